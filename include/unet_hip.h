@@ -1,0 +1,161 @@
+/*
+ * unet_hip.h -- C ABI of libunet_hip.so: hand-written CDNA4 (gfx950) kernels for the
+ * CondUNet1D hot path of AliZareh-CoE/Unet.
+ *
+ * The reference has no FFI: its "operator API" is torch.nn calls made from models.py.
+ * Each entry point below therefore cites the reference call site(s) it replaces.  The
+ * Python host (unet_amd/ops.py) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless
+ *     the name ends in _host
+ *   - activations are channels-last  [n][rows][ld]  ("NLC"), ld >= channels
+ *   - dtype: UNET_BF16 = bf16 storage, bf16 MFMA, fp32 accumulate;
+ *            UNET_F32  = fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32)
+ *   - the library never allocates or frees device memory, never synchronises the
+ *     device, keeps no pointer after return, and launches only on `stream`
+ *   - return 0 on success; otherwise a negative code and unet_last_error() (thread
+ *     local) holds a message.  No C++ exception crosses the boundary.
+ */
+#ifndef UNET_HIP_H
+#define UNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNET_ABI_VERSION 1
+#define UNET_MAX_TAPS 32
+
+enum { UNET_BF16 = 0, UNET_F32 = 1 };
+enum { UNET_ACT_NONE = 0, UNET_ACT_RELU = 1, UNET_ACT_LEAKY = 2, UNET_ACT_GELU = 3,
+       UNET_ACT_SILU = 4, UNET_ACT_MISH = 5 };  /* models.py:59-65 get_activation */
+
+int unet_abi_version(void);
+const char* unet_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Generic tap-list convolution (implicit GEMM on MFMA).  One descriptor covers
+ *   Conv1d k=1/3 stride 1/2                     models.py:558,3032,3038,3043,492,495,605,910
+ *   4-branch dilated k=7 conv, taps merged       models.py:692-699,752-759
+ *   ConvTranspose1d k=4 s=2 p=1 (two phases)     models.py:592,881
+ *   and the data-gradients of all of them (transposed weights, mirrored taps).
+ *
+ *   y[n, up*m + phase_j, co] = bias[co] + res[n, up*m+phase_j, co]
+ *        + sum_{taps j of that phase} sum_ci  W_j[co][ci] * x[n, stride*m + off_j, ci]
+ *   x rows outside [0, l_in) read as zero.  x is the channel-concatenation of two
+ *   sources (c2 may be 0): torch.cat([x, skip], 1) of models.py:624,930 is never built.
+ * ---------------------------------------------------------------------------------- */
+typedef struct UnetConvDesc {
+  int32_t dtype;
+  int32_t n;                    /* windows */
+  int32_t l_in;                 /* valid input rows per window */
+  int32_t c1, c2;               /* channels of source 1 / source 2 */
+  int32_t x1_ld, x2_ld;         /* row pitch (elements) */
+  int64_t x1_ns, x2_ns;         /* window stride (elements) */
+  int32_t l_out, c_out;
+  int32_t y_ld;  int64_t y_ns;
+  int32_t res_ld; int64_t res_ns;
+  int32_t stride, up;
+  int32_t n_taps;               /* taps must be grouped by phase, phase 0 first */
+  int32_t tap_off[UNET_MAX_TAPS];
+  int32_t tap_phase[UNET_MAX_TAPS];
+  int32_t act;                  /* epilogue activation (UNET_ACT_*) */
+} UnetConvDesc;
+
+/* bytes of the packed weight image unet_conv1d_fwd expects for (dtype, n_taps, rows=c_out, c1, c2) */
+size_t unet_conv1d_packed_bytes(int32_t dtype, int32_t n_taps, int32_t rows, int32_t c1, int32_t c2);
+
+/* Pack fp32 weights w[tap][row][col] (arbitrary element strides) into the tile-major, LDS-image
+ * layout the MFMA kernels stream with global_load_lds.  Packed tap t takes logical tap
+ * tap_src_host[t]; packed rows are logical rows [row_lo, row_lo+rows); packed K is
+ * cols [col_lo, col_lo+c1) then [col_lo+c1, col_lo+c1+c2), each zero-padded to the K-chunk.
+ * Forward packs (row=co, col=ci); data-grad packs the transpose (row=ci, col=co) via strides. */
+int unet_conv1d_pack(int32_t dtype, const float* w, int64_t tap_stride, int64_t row_stride,
+                     int64_t col_stride, int32_t n_taps, const int32_t* tap_src_host,
+                     int32_t row_lo, int32_t rows, int32_t col_lo, int32_t c1, int32_t c2,
+                     void* packed, void* stream);
+
+int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void* x2, const void* w_packed,
+                    const float* bias, const void* res, void* y, void* stream);
+
+/* Weight gradient:  dw[j][co][ci] (fp32, contiguous, ci over c1+c2) =
+ *   sum_n sum_m dy[n, up*m+phase_j, co] * x[n, stride*m+off_j, ci]
+ * d describes the FORWARD conv (dy has d->l_out rows, d->c_out channels, pitch y_ld/y_ns).
+ * workspace: split-K slabs, unet_conv1d_wgrad_workspace_bytes(d) bytes. */
+size_t unet_conv1d_wgrad_workspace_bytes(const UnetConvDesc* d);
+int unet_conv1d_wgrad(const UnetConvDesc* d, const void* x1, const void* x2, const void* dy,
+                      float* dw, void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Channels-last streaming kernels (HBM-bound).  "part" outputs are per-row-chunk partial
+ * sums  [n][UNET_PARTS(rows)][c]  fp32; the caller adds them over the middle axis (tiny).
+ * ---------------------------------------------------------------------------------- */
+int32_t unet_parts(int32_t rows);   /* number of row chunks used for partial sums */
+
+/* models.py:3235 z-score statistics over T of an NCL tensor x[n][c][t] (dtype in_dtype):
+ * mean[n][c] and rstd[n][c] = 1/(std_unbiased + eps), fp32 (also the stats of
+ * SessionAdaptiveScaling, models.py:2058-2059, and per_channel_normalize, train.py:476-495). */
+int unet_ncl_moments(int32_t in_dtype, const void* x, float* mean, float* rstd, int32_t n, int32_t c,
+                     int32_t t, float eps, void* stream);
+/* layout change into the kernels' channels-last form, with the z-score applied on the way:
+ * y[n][t][c] (dtype) = (x[n][c][t] - sub[n][c]) * mul[n][c]   (sub/mul NULL = plain transpose) */
+int unet_ncl_to_nlc(int32_t in_dtype, int32_t dtype, const void* x, const float* sub, const float* mul,
+                    void* y, int32_t n, int32_t c, int32_t t, void* stream);
+/* and back out at the model boundary (models.py:3363-3370: residual already added by the outc
+ * epilogue; ga/be carry SessionAdaptiveScaling's gamma/beta, models.py:2068):
+ * y[n][c][t] (out_dtype) = ga[n][c]*x[n][t][c] + gb[n][c]*x2[n][t][c] + be[n][c]
+ * ga/be NULL = identity; x2/gb NULL = absent (x2 is used by the z-score backward). */
+int unet_nlc_to_ncl(int32_t dtype, int32_t out_dtype, const void* x, const void* x2, const float* ga,
+                    const float* gb, const float* be, void* y, int32_t n, int32_t c, int32_t t,
+                    void* stream);
+
+/* per-(window, channel) sums for BatchNorm/InstanceNorm/GroupNorm statistics
+ * (models.py:537-555, 801-817):  s1 = sum_t y, s2 = sum_t y^2 */
+int unet_rowstats(int32_t dtype, const void* y, float* s1_part, float* s2_part, int32_t n,
+                  int32_t rows, int32_t c, void* stream);
+
+/* z = act(a[n][c]*y + b[n][c]); pool_part = partial sum_t z  (norm-apply + GELU + SE squeeze,
+ * models.py:559-560, 827, 649/660).  pool_part may be NULL. */
+int unet_affine_act_fwd(int32_t dtype, const void* y, const float* a, const float* b, int32_t act,
+                        void* z, float* pool_part, int32_t n, int32_t rows, int32_t c, void* stream);
+/* g = (dz + dpool[n][c]) * act'(a*y+b);  g1 = sum_t g, g2 = sum_t g*y  (partials) */
+int unet_affine_act_bwd_reduce(int32_t dtype, const void* y, const void* dz, const float* dpool,
+                               const float* a, const float* b, int32_t act, float* g1_part,
+                               float* g2_part, int32_t n, int32_t rows, int32_t c, void* stream);
+/* dy = ca[n][c]*g + cb[n][c]*y + cc[n][c] */
+int unet_affine_act_bwd_apply(int32_t dtype, const void* y, const void* dz, const float* dpool,
+                              const float* a, const float* b, int32_t act, const float* ca,
+                              const float* cb, const float* cc, void* dy, int32_t n, int32_t rows,
+                              int32_t c, void* stream);
+
+/* out = x * s[n][c]  (SE excite, models.py:662);  bwd: dx = dout*s, ds_part = sum_t dout*x */
+int unet_scale_fwd(int32_t dtype, const void* x, const float* s, void* out, int32_t n, int32_t rows,
+                   int32_t c, void* stream);
+int unet_scale_bwd(int32_t dtype, const void* x, const void* dout, const float* s, void* dx,
+                   float* ds_part, int32_t n, int32_t rows, int32_t c, void* stream);
+
+/* FiLM channel softmax (models.py:514-515): h[n,t,:] = softmax_c(q[n,t,:]*kk[n,:]) * v[n,:] */
+int unet_film_softmax_fwd(int32_t dtype, const void* q, const float* kk, const float* v, void* h,
+                          int32_t n, int32_t rows, int32_t c, void* stream);
+int unet_film_softmax_bwd(int32_t dtype, const void* q, const void* dh, const float* kk,
+                          const float* v, void* dq, float* dkk_part, float* dv_part, int32_t n,
+                          int32_t rows, int32_t c, void* stream);
+
+/* out = res + g[n][c]*o  (models.py:517);  bwd: do = g*dout, dg_part = sum_t dout*o */
+int unet_gated_add_fwd(int32_t dtype, const void* res, const void* o, const float* g, void* out,
+                       int32_t n, int32_t rows, int32_t c, void* stream);
+int unet_gated_add_bwd(int32_t dtype, const void* o, const void* dout, const float* g, void* d_o,
+                       float* dg_part, int32_t n, int32_t rows, int32_t c, void* stream);
+
+/* column sums over all rows of all windows: out_part[n][parts][c] = partial sum_t x  (bias grads) */
+int unet_colsum(int32_t dtype, const void* x, float* out_part, int32_t n, int32_t rows, int32_t c,
+                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNET_HIP_H */

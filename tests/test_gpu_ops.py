@@ -1,0 +1,228 @@
+"""Kernel-level parity (GPU): each HIP op through the C ABI against plain torch fp32 on the CPU.
+fp32 kernels use the exact-f32 MFMA (an fmaf chain), so tolerances are ~1e-5 relative; the
+bf16 kernels are checked against the same reference evaluated on bf16-rounded inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from unet_amd import ops
+    return ops
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _ref_conv(x_ncl, w, b, stride, dilation, k):
+    return F.conv1d(x_ncl, w, b, stride=stride, padding=(k - 1) * dilation // 2, dilation=dilation)
+
+
+CONV_CASES = [
+    # (n, cin, cout, L, k, stride, dilation)
+    (2, 8, 8, 50, 3, 1, 1),
+    (2, 32, 256, 300, 3, 1, 1),
+    (3, 96, 160, 257, 3, 2, 1),
+    (2, 64, 64, 128, 1, 1, 1),
+    (2, 70, 36, 131, 7, 1, 4),
+    (2, 128, 130, 200, 7, 2, 16),
+    (1, 256, 256, 384, 7, 1, 32),
+    (2, 6, 4, 37, 3, 2, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case, dtype):
+    ops = _ops()
+    n, cin, cout, L, k, stride, dil = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(n, cin, L, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / (cin * k) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    wr = (w.bfloat16().float() if dtype == torch.bfloat16 else w).clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    yr = _ref_conv(xr, wr, br, stride, dil, k)
+    dy = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    yr.backward(dy)
+
+    xd = x.permute(0, 2, 1).contiguous().to("cuda", dtype).requires_grad_(True)
+    wd = w.cuda().requires_grad_(True)
+    bd = b.cuda().requires_grad_(True)
+    geom = ops.geom_conv(k, stride, dil)
+    y = ops.conv(xd, wd.permute(2, 0, 1), bd, geom, yr.shape[-1])
+    assert y.shape == (n, yr.shape[-1], cout)
+    y.backward(dy.permute(0, 2, 1).contiguous().to("cuda", dtype))
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert rel(y.permute(0, 2, 1), yr) < tol
+    assert rel(xd.grad.permute(0, 2, 1), xr.grad) < tol
+    assert rel(wd.grad, wr.grad) < tol
+    assert rel(bd.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 16, 8, 33), (2, 128, 96, 200), (1, 512, 256, 64)])
+def test_conv_transpose(shape, dtype):
+    ops = _ops()
+    n, cin, cout, L = shape
+    g = torch.Generator().manual_seed(L)
+    x = torch.randn(n, cin, L, generator=g)
+    w = torch.randn(cin, cout, 4, generator=g) / (cin * 2) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(n, cout, 2 * L, generator=g)
+    if dtype == torch.bfloat16:
+        x, w, res = x.bfloat16().float(), w.bfloat16().float(), res.bfloat16().float()
+    xr, wr, br, rr = (t.clone().requires_grad_(True) for t in (x, w, b, res))
+    yr = F.conv_transpose1d(xr, wr, br, stride=2, padding=1) + rr
+    dy = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    yr.backward(dy)
+    geom, kidx = ops.geom_convt_k4s2p1()
+    xd = x.permute(0, 2, 1).contiguous().to("cuda", dtype).requires_grad_(True)
+    rd = res.permute(0, 2, 1).contiguous().to("cuda", dtype).requires_grad_(True)
+    wd = w.cuda().requires_grad_(True)
+    bd = b.cuda().requires_grad_(True)
+    y = ops.conv(xd, wd.permute(2, 1, 0)[list(kidx)], bd, geom, 2 * L, res=rd)
+    y.backward(dy.permute(0, 2, 1).contiguous().to("cuda", dtype))
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert rel(y.permute(0, 2, 1), yr) < tol
+    assert rel(xd.grad.permute(0, 2, 1), xr.grad) < tol
+    assert rel(wd.grad, wr.grad) < tol
+    assert rel(bd.grad, br.grad) < tol
+    assert rel(rd.grad.permute(0, 2, 1), rr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_merged_dilated_concat(stride, dtype):
+    """4-branch dilated conv (models.py:752-759) on a two-source (concat) input."""
+    import unet_amd
+    n, c1, c2, cout, L = 2, 40, 24, 72, 301
+    torch.manual_seed(5)
+    blk = unet_amd.MultiScaleDilatedConv1d(c1 + c2, cout, 7, stride, (1, 4, 16, 32))
+    with torch.no_grad():
+        blk.scale_weights.copy_(torch.tensor([0.1, 0.5, -0.3, 0.2]))
+    xa, xb = torch.randn(n, c1, L), torch.randn(n, c2, L)
+    if dtype == torch.bfloat16:
+        xa, xb = xa.bfloat16().float(), xb.bfloat16().float()
+    xar, xbr = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in blk.named_parameters()}
+    wsm = torch.softmax(params["scale_weights"], 0)
+    xcat = torch.cat([xar, xbr], 1)
+    yr = 0
+    for i, d in enumerate((1, 4, 16, 32)):
+        yr = yr + wsm[i] * F.conv1d(xcat, params[f"branches.{i}.conv.weight"], params[f"branches.{i}.conv.bias"],
+                                    stride=stride, padding=3 * d, dilation=d)
+    dy = torch.randn(yr.shape)
+    yr.backward(dy)
+    blk = blk.cuda()
+    xad = xa.permute(0, 2, 1).contiguous().to("cuda", dtype).requires_grad_(True)
+    xbd = xb.permute(0, 2, 1).contiguous().to("cuda", dtype).requires_grad_(True)
+    y = blk.forward_nlc(xad, xbd)
+    y.backward(dy.permute(0, 2, 1).contiguous().to("cuda", dtype))
+    tol = 3e-5 if dtype == torch.float32 else 1.5e-2
+    assert rel(y.permute(0, 2, 1), yr) < tol
+    assert rel(xad.grad.permute(0, 2, 1), xar.grad) < tol
+    assert rel(xbd.grad.permute(0, 2, 1), xbr.grad) < tol
+    for k, p in blk.named_parameters():
+        assert rel(p.grad, params[k].grad) < tol, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c", [8, 6, 256, 1000])
+def test_film_softmax(c, dtype):
+    ops = _ops()
+    n, L = 2, 150
+    torch.manual_seed(c)
+    q = torch.randn(n, L, c) * 2
+    if dtype == torch.bfloat16:
+        q = q.bfloat16().float()
+    kk, v = torch.randn(n, c), torch.randn(n, c)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, kk, v))
+    hr = torch.softmax(qr * kr[:, None, :], dim=-1) * vr[:, None, :]
+    dh = torch.randn(hr.shape)
+    if dtype == torch.bfloat16:
+        dh = dh.bfloat16().float()
+    hr.backward(dh)
+    qd = q.to("cuda", dtype).requires_grad_(True)
+    kd, vd = kk.cuda().requires_grad_(True), v.cuda().requires_grad_(True)
+    h = ops.FilmSoftmaxFn.apply(qd, kd, vd)
+    h.backward(dh.to("cuda", dtype))
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel(h, hr) < tol
+    assert rel(qd.grad, qr.grad) < tol * 2
+    assert rel(kd.grad, kr.grad) < tol * 2
+    assert rel(vd.grad, vr.grad) < tol * 2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scale_gated_add_activation(dtype):
+    ops = _ops()
+    n, L, c = 3, 200, 48
+    torch.manual_seed(1)
+    x, o = torch.randn(n, L, c), torch.randn(n, L, c)
+    if dtype == torch.bfloat16:
+        x, o = x.bfloat16().float(), o.bfloat16().float()
+    s = torch.rand(n, c)
+    xr, orr, sr = (t.clone().requires_grad_(True) for t in (x, o, s))
+    yr = F.gelu(xr * sr[:, None, :]) + sr[:, None, :] * orr
+    dy = torch.randn(yr.shape)
+    yr.backward(dy)
+    xd = x.to("cuda", dtype).requires_grad_(True)
+    od = o.to("cuda", dtype).requires_grad_(True)
+    sd = s.cuda().requires_grad_(True)
+    t1 = ops.activation(ops.ScaleFn.apply(xd, sd), 3)
+    y = ops.GatedAddFn.apply(t1, od, sd)
+    y.backward(dy.to("cuda", dtype))
+    tol = 1e-5 if dtype == torch.float32 else 1.5e-2
+    assert rel(y, yr) < tol
+    assert rel(xd.grad, xr.grad) < tol
+    assert rel(od.grad, orr.grad) < tol
+    assert rel(sd.grad, sr.grad) < tol * 2
+
+
+@pytest.mark.parametrize("act", ["relu", "leaky_relu", "gelu", "silu", "mish"])
+def test_activations(act):
+    ops = _ops()
+    from unet_amd._lib import ACT_IDS
+    from oracle import condunet_oracle as O
+    x = torch.linspace(-6, 6, 4 * 50 * 16).reshape(4, 50, 16)
+    xr = x.clone().requires_grad_(True)
+    yr = O.act(act, xr)
+    yr.backward(torch.ones_like(yr))
+    xd = x.cuda().requires_grad_(True)
+    y = ops.activation(xd, ACT_IDS[act])
+    y.backward(torch.ones_like(y))
+    assert (y.cpu() - yr).abs().max() < 2e-6
+    assert (xd.grad.cpu() - xr.grad).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("in_dtype", [torch.float32, torch.bfloat16])
+def test_zscore_boundary(in_dtype):
+    ops = _ops()
+    from oracle import condunet_oracle as O
+    torch.manual_seed(2)
+    ob = (torch.randn(3, 10, 333) * 2 + 0.5)
+    if in_dtype == torch.bfloat16:
+        ob = ob.bfloat16().float()
+    obr = ob.clone().requires_grad_(True)
+    xr = O.zscore(obr)
+    dx = torch.randn(xr.shape)
+    xr.backward(dx)
+    obd = ob.to("cuda", in_dtype).requires_grad_(True)
+    x = ops.ZScoreInFn.apply(obd, torch.float32)
+    x.backward(dx.permute(0, 2, 1).contiguous().cuda())
+    assert rel(x.permute(0, 2, 1), xr) < 1e-5
+    assert rel(obd.grad, obr.grad) < (1e-4 if in_dtype == torch.float32 else 1e-2)
+    y = ops.ToNCLFn.apply(x.detach(), torch.float32)
+    assert torch.equal(y, x.detach().permute(0, 2, 1))

@@ -1,0 +1,158 @@
+// Shared device/host helpers for libunet_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/unet_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// ---- error plumbing (error.cpp) -------------------------------------------------------------
+void unet_set_error(const char* fmt, ...);
+#define UNET_REQUIRE(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      unet_set_error(__VA_ARGS__);         \
+      return -1;                           \
+    }                                      \
+  } while (0)
+#define UNET_LAUNCH_CHECK(what)                                              \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      unet_set_error("%s: launch failed: %s", what, hipGetErrorString(e__)); \
+      return -2;                                                             \
+    }                                                                        \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- element access by dtype ----------------------------------------------------------------
+template <bool F32> struct Elem;
+template <> struct Elem<false> {
+  typedef __bf16 T;
+  static constexpr int SIZE = 2;
+  static constexpr int EPC = 8;  // elements per 16-byte chunk
+};
+template <> struct Elem<true> {
+  typedef float T;
+  static constexpr int SIZE = 4;
+  static constexpr int EPC = 4;
+};
+
+__device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+__device__ __forceinline__ float to_f32(float v) { return v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+
+// vector of V elements <-> float[V]   (V*sizeof(T) in {2,4,8,16})
+template <typename T, int V> struct VecIO {
+  __device__ static __forceinline__ void load(const T* p, float (&f)[V]) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) f[i] = to_f32(p[i]);
+  }
+  __device__ static __forceinline__ void store(T* p, const float (&f)[V]) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) p[i] = from_f32<T>(f[i]);
+  }
+};
+template <> struct VecIO<__bf16, 8> {
+  __device__ static __forceinline__ void load(const __bf16* p, float (&f)[8]) {
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+  }
+  __device__ static __forceinline__ void store(__bf16* p, const float (&f)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (__bf16)f[i];
+    *reinterpret_cast<bf16x8*>(p) = v;
+  }
+};
+template <> struct VecIO<__bf16, 4> {
+  __device__ static __forceinline__ void load(const __bf16* p, float (&f)[4]) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = (float)v[i];
+  }
+  __device__ static __forceinline__ void store(__bf16* p, const float (&f)[4]) {
+    bf16x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (__bf16)f[i];
+    *reinterpret_cast<bf16x4*>(p) = v;
+  }
+};
+template <> struct VecIO<float, 4> {
+  __device__ static __forceinline__ void load(const float* p, float (&f)[4]) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = v[i];
+  }
+  __device__ static __forceinline__ void store(float* p, const float (&f)[4]) {
+    f32x4 v = {f[0], f[1], f[2], f[3]};
+    *reinterpret_cast<f32x4*>(p) = v;
+  }
+};
+
+// ---- activations (models.py:59-65) and their derivatives ------------------------------------
+__device__ __forceinline__ float act_fwd(int act, float x) {
+  switch (act) {
+    case UNET_ACT_RELU: return x > 0.f ? x : 0.f;
+    case UNET_ACT_LEAKY: return x > 0.f ? x : 0.2f * x;
+    case UNET_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    case UNET_ACT_SILU: return x / (1.f + __expf(-x));
+    case UNET_ACT_MISH: {
+      float sp = x > 20.f ? x : log1pf(__expf(x));
+      return x * tanhf(sp);
+    }
+    default: return x;
+  }
+}
+__device__ __forceinline__ float act_bwd(int act, float x) {
+  switch (act) {
+    case UNET_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case UNET_ACT_LEAKY: return x > 0.f ? 1.f : 0.2f;
+    case UNET_ACT_GELU:
+      return 0.5f * (1.f + erff(x * 0.70710678118654752f)) +
+             x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    case UNET_ACT_SILU: {
+      float s = 1.f / (1.f + __expf(-x));
+      return s * (1.f + x * (1.f - s));
+    }
+    case UNET_ACT_MISH: {
+      float sp = x > 20.f ? x : log1pf(__expf(x));
+      float t = tanhf(sp);
+      float s = 1.f / (1.f + __expf(-x));
+      return t + x * (1.f - t * t) * s;
+    }
+    default: return 1.f;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// bijective XCD-aware remap of a 1-D grid: blocks that share an XCD (id % 8) get a
+// contiguous range of work ids, so neighbouring tiles hit the same L2.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}

@@ -1,0 +1,697 @@
+// Implicit-GEMM tap-list convolution on CDNA4 matrix cores (gfx950).
+//
+// One kernel family covers Conv1d (k=1/3/merged 4-branch dilated k=7, stride 1/2),
+// ConvTranspose1d k4 s2 p1 (two output phases) and all of their data gradients; a second
+// family computes weight gradients.  See include/unet_hip.h for the math and the reference
+// call sites.
+//
+// Layout decisions (MI355X-first, not a translation of the reference's NCL tensors):
+//   * activations are channels-last [n][row][c]: the GEMM reduction dim (channels) is the
+//     contiguous one, so an MFMA operand fragment (8 consecutive k) is ONE 16-byte LDS read
+//     at any tap shift -- dilation/stride only move the LDS row index.
+//   * per K-chunk the input halo tile (all rows any tap of the phase touches) is staged once
+//     in LDS and reused by every tap (23 taps for the merged dilated conv).
+//   * weights are pre-packed (unet_conv1d_pack) tile-major in the exact swizzled LDS image, so
+//     a 16 KB tile is one contiguous global range streamed with global_load_lds (LDS-DMA,
+//     no VGPR round trip), double-buffered against the MFMAs.
+//   * LDS rows are 128 B; 16-B chunk index is XORed with (row>>1)&7 so that the 16 rows a
+//     ds_read_b128 lane group touches land on 16 distinct 16-B slots of the 256-B bank row.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BM = 128;            // output channels per block
+constexpr int WTILE_BYTES = 16384; // 128 rows x 128 B
+constexpr int THREADS = 256;
+
+struct ConvK {
+  const char* x1; const char* x2; const char* wp; const float* bias; const char* res; char* y;
+  long long x1_ns, x2_ns, y_ns, res_ns;  // elements
+  int x1_ld, x2_ld, y_ld, res_ld;
+  int c1, c2, kc1, kctot;
+  int l_in, l_out, c_out, n;
+  int stride, up, act;
+  int mtiles;
+  int ptiles[2];
+  int pbeg[3];
+  int mcount[2];
+  int omin[2], omax[2];
+  int x1_vec, x2_vec, y_vec, res_vec;
+  int tap_off[UNET_MAX_TAPS];
+};
+
+template <bool F32> struct Mma;
+template <> struct Mma<false> {
+  typedef bf16x8 AB;
+  __device__ static __forceinline__ AB ld(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+  __device__ static __forceinline__ f32x4 mma(AB a, AB b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<true> {
+  typedef float AB;
+  __device__ static __forceinline__ AB ld(const char* p) { return *reinterpret_cast<const float*>(p); }
+  __device__ static __forceinline__ f32x4 mma(AB a, AB b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+// ---------------------------------------------------------------------------------------------
+// forward / data-grad kernel
+// ---------------------------------------------------------------------------------------------
+template <bool F32, int BN>
+__global__ __launch_bounds__(THREADS, 2) void conv_fwd_kernel(const ConvK p) {
+  typedef typename Elem<F32>::T T;
+  constexpr int EPC = Elem<F32>::EPC;
+  constexpr int KC = EPC * 8;          // K elements per 128-byte LDS row
+  constexpr int NI = BN / 32;          // 16-wide position fragments per wave
+  constexpr int KSTEPS = F32 ? 8 : 2;  // MFMA k-steps per 128-byte row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wbuf = smem;
+  char* xbuf = smem + 2 * WTILE_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  // ---- which tile -------------------------------------------------------------------------
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int ppw = p.ptiles[0] + p.ptiles[1];
+  const int per_mt = p.n * ppw;
+  const int mt = wg / per_mt;
+  int rem = wg - mt * per_mt;
+  const int n = rem / ppw;
+  int pt = rem - n * ppw;
+  int phase = 0;
+  if (pt >= p.ptiles[0]) { phase = 1; pt -= p.ptiles[0]; }
+  const int m0 = pt * BN;
+  const int tb = p.pbeg[phase];
+  const int nt = p.pbeg[phase + 1] - tb;
+  const int omin = p.omin[phase];
+  const int R = p.stride * (BN - 1) + p.omax[phase] - omin + 1;
+  const int rowbase = p.stride * m0 + omin;
+
+  f32x4 acc[4][NI];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging helpers ---------------------------------------------------------------------
+  auto issue_w = [&](int step, int buf) {
+    const int kc = step / nt, j = step - kc * nt;
+    const char* tile = p.wp + ((size_t)((tb + j) * p.mtiles + mt) * p.kctot + kc) * WTILE_BYTES;
+    char* dst = wbuf + buf * WTILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = wave * 4 + i;  // 1 KiB per wave-instruction
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(tile + piece * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+    }
+  };
+
+  auto stage_x = [&](int kc) {
+    const char* src; int ld, csrc, cbase, vec; long long ns;
+    if (kc < p.kc1) { src = p.x1; ld = p.x1_ld; csrc = p.c1; cbase = kc * KC; ns = p.x1_ns; vec = p.x1_vec; }
+    else { src = p.x2; ld = p.x2_ld; csrc = p.c2; cbase = (kc - p.kc1) * KC; ns = p.x2_ns; vec = p.x2_vec; }
+    const T* base = reinterpret_cast<const T*>(src) + (long long)n * ns;
+    for (int idx = tid; idx < R * 8; idx += THREADS) {
+      const int i = idx >> 3, c = idx & 7;
+      const int g = rowbase + i, e0 = cbase + c * EPC;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (g >= 0 && g < p.l_in && e0 < csrc) {
+        const T* ptr = base + (long long)g * ld + e0;
+        if (vec && e0 + EPC <= csrc) {
+          v = *reinterpret_cast<const u32x4*>(ptr);
+        } else {
+          union { u32x4 u; T e[EPC]; } tmp;
+          tmp.u = u32x4{0u, 0u, 0u, 0u};
+          for (int k = 0; k < EPC; ++k)
+            if (e0 + k < csrc) tmp.e[k] = ptr[k];
+          v = tmp.u;
+        }
+      }
+      *reinterpret_cast<u32x4*>(xbuf + i * 128 + (swz(i, c) << 4)) = v;
+    }
+  };
+
+  // per-lane A-fragment byte offset inside a W tile (tap independent)
+  int a_off[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) a_off[mi] = (wm * 64 + mi * 16 + l15) * 128;
+  const int a_sw = (l15 >> 1) & 7;  // (row>>1)&7 for rows = 16k + l15
+
+  auto compute = [&](int step, int buf) {
+    const int kc = step / nt, j = step - kc * nt;
+    (void)kc;
+    const int d = p.tap_off[tb + j] - omin;
+    const char* wb = wbuf + buf * WTILE_BYTES;
+    int b_row[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b_row[ni] = p.stride * (wn * (BN / 2) + ni * 16 + l15) + d;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int chunk = F32 ? ks : ks * 4 + lq;
+      const int sub = F32 ? lq * 4 : 0;
+      typename Mma<F32>::AB a[4], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) a[mi] = Mma<F32>::ld(wb + a_off[mi] + ((chunk ^ a_sw) << 4) + sub);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        b[ni] = Mma<F32>::ld(xbuf + b_row[ni] * 128 + (swz(b_row[ni], chunk) << 4) + sub);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mma<F32>::mma(a[mi], b[ni], acc[mi][ni]);
+    }
+  };
+
+  // ---- main loop: steps = K-chunks x taps; W double-buffered by LDS-DMA ----------------------
+  const int steps = p.kctot * nt;
+  if (steps > 0) {
+    issue_w(0, 0);
+    stage_x(0);
+    for (int s = 0; s < steps; ++s) {
+      __syncthreads();  // W(s) landed (vmcnt(0) by the compiler), X tile visible, buf[(s+1)&1] free
+      if (s + 1 < steps) issue_w(s + 1, (s + 1) & 1);
+      compute(s, s & 1);
+      if (s + 1 < steps && (s + 1) % nt == 0) {
+        __syncthreads();  // every wave is done with the X tile of this K-chunk
+        stage_x((s + 1) / nt);
+      }
+    }
+  }
+
+  // ---- epilogue: bias, residual, activation, store (4 consecutive channels per lane) --------
+  T* ybase = reinterpret_cast<T*>(p.y) + (long long)n * p.y_ns;
+  const T* rbase = p.res ? reinterpret_cast<const T*>(p.res) + (long long)n * p.res_ns : nullptr;
+  const int mcount = p.mcount[phase];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int m = m0 + wn * (BN / 2) + ni * 16 + l15;
+    if (m >= mcount) continue;
+    const long long o = (long long)p.up * m + phase;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int co = mt * BM + wm * 64 + mi * 16 + lq * 4;
+      if (co >= p.c_out) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r];
+      const bool full = co + 4 <= p.c_out;
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < p.c_out) v[r] += p.bias[co + r];
+      }
+      if (rbase) {
+        const T* rp = rbase + o * p.res_ld + co;
+        if (full && p.res_vec) {
+          float rv[4];
+          VecIO<T, 4>::load(rp, rv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += rv[r];
+        } else {
+          for (int r = 0; r < 4; ++r)
+            if (co + r < p.c_out) v[r] += to_f32(rp[r]);
+        }
+      }
+      if (p.act != UNET_ACT_NONE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
+      }
+      T* yp = ybase + o * p.y_ld + co;
+      if (full && p.y_vec) {
+        VecIO<T, 4>::store(yp, v);
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (co + r < p.c_out) yp[r] = from_f32<T>(v[r]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing:  fp32 w[tap][row][col] (strided)  ->  [tap][row tile][K chunk][128 rows][8 chunks x 16 B]
+// in the swizzled LDS image of conv_fwd_kernel.
+// ---------------------------------------------------------------------------------------------
+struct PackK {
+  const float* w; long long ts, rs, cs;
+  int n_taps, row_lo, rows, col_lo, c1, c2, kc1, kctot, mtiles;
+  int tap_src[UNET_MAX_TAPS];
+  char* out;
+};
+
+template <bool F32>
+__global__ __launch_bounds__(256) void conv_pack_kernel(const PackK p) {
+  typedef typename Elem<F32>::T T;
+  constexpr int EPC = Elem<F32>::EPC;
+  constexpr int KC = EPC * 8;
+  const long long total = (long long)p.n_taps * p.mtiles * p.kctot * 1024;  // 16-B chunks
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * 256) {
+    const int cp = (int)(idx & 7);           // physical chunk in the row
+    const int row = (int)((idx >> 3) & 127);
+    long long t = idx >> 10;
+    const int kc = (int)(t % p.kctot); t /= p.kctot;
+    const int mt = (int)(t % p.mtiles);
+    const int tap = (int)(t / p.mtiles);
+    const int c = swz(row, cp);              // logical chunk (XOR is an involution)
+    const int r = mt * 128 + row;
+    union { u32x4 u; T e[EPC]; } v;
+    v.u = u32x4{0u, 0u, 0u, 0u};
+    if (r < p.rows) {
+      const float* src = p.w + (long long)p.tap_src[tap] * p.ts + (long long)(p.row_lo + r) * p.rs;
+#pragma unroll
+      for (int k = 0; k < EPC; ++k) {
+        int kk, col = -1;
+        if (kc < p.kc1) { kk = kc * KC + c * EPC + k; if (kk < p.c1) col = p.col_lo + kk; }
+        else { kk = (kc - p.kc1) * KC + c * EPC + k; if (kk < p.c2) col = p.col_lo + p.c1 + kk; }
+        if (col >= 0) v.e[k] = from_f32<T>(src[(long long)col * p.cs]);
+      }
+    }
+    *reinterpret_cast<u32x4*>(p.out + idx * 16) = v.u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight-gradient kernel: dW_j[co][ci] = sum_{n,m} dy[n, up*m+phase_j, co] * x[n, stride*m+off_j, ci]
+// The reduction runs over positions, i.e. over LDS ROWS of channels-last tiles: both operands
+// are read transposed (ds_read_b64_tr_b16 for bf16; plain b32 column reads for fp32).
+// Split-K over (window, position-chunk) items into fp32 slabs; a second kernel adds the slabs
+// (deterministic, no float atomics).
+// ---------------------------------------------------------------------------------------------
+struct WgK {
+  const char* x1; const char* x2; const char* dy; float* slab;
+  long long x1_ns, x2_ns, dy_ns;
+  int x1_ld, x2_ld, dy_ld;
+  int c1, c2, kt1, kttot;   // 128-channel input tiles per source
+  int l_in, c_out, n;
+  int stride, up;
+  int mtiles, n_taps, splits;
+  int mcount[2];
+  int x1_vec, x2_vec, dy_vec;
+  int tap_off[UNET_MAX_TAPS];
+  int tap_phase[UNET_MAX_TAPS];
+};
+
+__device__ __forceinline__ int swz_t(int row, int ch) { return ch ^ (((row & 3) << 2) | ((row >> 2) & 3)); }
+
+template <bool F32>
+__global__ __launch_bounds__(THREADS, 2) void conv_wgrad_kernel(const WgK p) {
+  typedef typename Elem<F32>::T T;
+  constexpr int EPC = Elem<F32>::EPC;
+  constexpr int BKP = F32 ? 32 : 64;    // positions per staged tile
+  constexpr int ROWB = F32 ? 512 : 256; // bytes per LDS row (128 channels)
+  constexpr int CPR = ROWB / 16;        // 16-B chunks per row
+  constexpr int NLD = BKP * CPR / THREADS;  // chunks per thread per tile (= 4)
+  __shared__ __attribute__((aligned(16))) char lds[2 * BKP * ROWB];
+  char* dyt = lds;
+  char* xt = lds + BKP * ROWB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  int wg = xcd_remap(blockIdx.x, gridDim.x);
+  // order: (mt, kt) slowest, then split, then tap fastest: blocks sharing an XCD at one time work on
+  // the same dy/x rows for different taps -> the operand rows are served from that XCD's L2.
+  const int j = wg % p.n_taps; wg /= p.n_taps;
+  const int split = wg % p.splits; wg /= p.splits;
+  const int kt = wg % p.kttot;
+  const int mt = wg / p.kttot;
+
+  const int phase = p.tap_phase[j], off = p.tap_off[j];
+  const int mcount = p.mcount[phase];
+  const int mchunks = (mcount + BKP - 1) / BKP;
+  const int items = p.n * mchunks;
+  const int per = (items + p.splits - 1) / p.splits;
+  const int it0 = split * per;
+  const int it1 = min(items, it0 + per);
+
+  const char* xsrc; int xld, xc, xc0, xvec; long long xns;
+  if (kt < p.kt1) { xsrc = p.x1; xld = p.x1_ld; xc = p.c1; xc0 = kt * 128; xns = p.x1_ns; xvec = p.x1_vec; }
+  else { xsrc = p.x2; xld = p.x2_ld; xc = p.c2; xc0 = (kt - p.kt1) * 128; xns = p.x2_ns; xvec = p.x2_vec; }
+  const int co0 = mt * 128;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 rdy[NLD], rx[NLD];
+
+  auto load_chunk = [&](const T* base, long long rowoff, bool rowok, int c0, int cmax, int vec) -> u32x4 {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (rowok && c0 < cmax) {
+      const T* ptr = base + rowoff + c0;
+      if (vec && c0 + EPC <= cmax) v = *reinterpret_cast<const u32x4*>(ptr);
+      else {
+        union { u32x4 u; T e[EPC]; } tmp;
+        tmp.u = u32x4{0u, 0u, 0u, 0u};
+        for (int k = 0; k < EPC; ++k)
+          if (c0 + k < cmax) tmp.e[k] = ptr[k];
+        v = tmp.u;
+      }
+    }
+    return v;
+  };
+
+  auto gload = [&](int item) {
+    const int n = item / mchunks, mc = item - n * mchunks;
+    const T* dyb = reinterpret_cast<const T*>(p.dy) + (long long)n * p.dy_ns;
+    const T* xb = reinterpret_cast<const T*>(xsrc) + (long long)n * xns;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * THREADS;
+      const int row = idx / CPR, ch = idx % CPR;
+      const int m = mc * BKP + row;
+      const bool mok = m < mcount;
+      const long long o = (long long)p.up * m + phase;
+      rdy[i] = load_chunk(dyb, o * p.dy_ld, mok, co0 + ch * EPC, p.c_out, p.dy_vec);
+      const long long g = (long long)p.stride * m + off;
+      rx[i] = load_chunk(xb, g * xld, mok && g >= 0 && g < p.l_in, xc0 + ch * EPC, xc, xvec);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * THREADS;
+      const int row = idx / CPR, ch = idx % CPR;
+      const int chp = F32 ? ch : swz_t(row, ch);
+      *reinterpret_cast<u32x4*>(dyt + row * ROWB + chp * 16) = rdy[i];
+      *reinterpret_cast<u32x4*>(xt + row * ROWB + chp * 16) = rx[i];
+    }
+  };
+
+  auto compute = [&]() {
+    if constexpr (F32) {
+#pragma unroll
+      for (int kk = 0; kk < BKP / 4; ++kk) {
+        const int row = kk * 4 + lq;
+        float a[4], b[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          a[mi] = *reinterpret_cast<const float*>(dyt + row * ROWB + (wm * 64 + mi * 16 + l15) * 4);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          b[ni] = *reinterpret_cast<const float*>(xt + row * ROWB + (wn * 64 + ni * 16 + l15) * 4);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+      }
+    } else {
+      // lane 4q+pp of each 16-lane group addresses row q, columns 4pp..4pp+3 of a 4x16 block;
+      // it receives column (lane&15), rows 0..3  (T10 of the CDNA4 guide)
+      const int q = l15 >> 2, pp = l15 & 3;
+#pragma unroll
+      for (int ks = 0; ks < BKP / 32; ++ks) {
+        const int r0 = ks * 32 + lq * 8 + q;
+        bf16x8 a[4], b[4];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int row = r0 + half * 4;
+          const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) {
+            const int c0 = (wm * 64 + mi * 16) >> 3;
+            s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(dyt + row * ROWB + (((c0 + (pp >> 1)) ^ sw) << 4) + 8 * (pp & 1)));
+            bf16x4 vb = __builtin_bit_cast(bf16x4, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[mi][half * 4 + e] = vb[e];
+          }
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const int c0 = (wn * 64 + ni * 16) >> 3;
+            s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(xt + row * ROWB + (((c0 + (pp >> 1)) ^ sw) << 4) + 8 * (pp & 1)));
+            bf16x4 vb = __builtin_bit_cast(bf16x4, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[ni][half * 4 + e] = vb[e];
+          }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+  };
+
+  if (it0 < it1) {
+    gload(it0);
+    for (int it = it0; it < it1; ++it) {
+      __syncthreads();   // previous compute finished reading LDS
+      lstore();
+      __syncthreads();
+      if (it + 1 < it1) gload(it + 1);  // in flight during the MFMAs
+      compute();
+    }
+  }
+
+  // ---- store the fp32 slab tile -------------------------------------------------------------
+  const int ctot = p.c1 + p.c2;
+  const int ci_base = (kt < p.kt1 ? 0 : p.c1) + xc0;  // logical input-channel index of tile column 0
+  float* slab = p.slab + ((long long)split * p.n_taps + j) * p.c_out * ctot;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int cl = xc0 + wn * 64 + ni * 16 + l15;  // channel within its source
+    if (cl >= xc) continue;
+    const int ci = ci_base - xc0 + cl;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wm * 64 + mi * 16 + lq * 4 + r;
+        if (co < p.c_out) slab[(long long)co * ctot + ci] = acc[mi][ni][r];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, float* out, long long count, int splits) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += slab[k * count + i];
+    out[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct Phases {
+  int pbeg[3]; int omin[2]; int omax[2]; int mcount[2];
+};
+
+int analyse(const UnetConvDesc* d, Phases* ph) {
+  UNET_REQUIRE(d->dtype == UNET_BF16 || d->dtype == UNET_F32, "conv: bad dtype %d", d->dtype);
+  UNET_REQUIRE(d->n > 0 && d->l_in > 0 && d->l_out > 0 && d->c1 > 0 && d->c2 >= 0 && d->c_out > 0,
+               "conv: non-positive dimension (n=%d l_in=%d l_out=%d c1=%d c2=%d c_out=%d)", d->n, d->l_in,
+               d->l_out, d->c1, d->c2, d->c_out);
+  UNET_REQUIRE(d->up == 1 || d->up == 2, "conv: up must be 1 or 2 (got %d)", d->up);
+  UNET_REQUIRE(d->stride == 1 || d->stride == 2, "conv: stride must be 1 or 2 (got %d)", d->stride);
+  UNET_REQUIRE(d->n_taps >= 0 && d->n_taps <= UNET_MAX_TAPS, "conv: n_taps %d out of range", d->n_taps);
+  UNET_REQUIRE(d->x1_ld >= d->c1 && (d->c2 == 0 || d->x2_ld >= d->c2) && d->y_ld >= d->c_out,
+               "conv: row pitch smaller than channel count");
+  int prev = 0;
+  ph->pbeg[0] = 0; ph->pbeg[1] = d->n_taps; ph->pbeg[2] = d->n_taps;
+  for (int r = 0; r < 2; ++r) { ph->omin[r] = 0; ph->omax[r] = 0; ph->mcount[r] = 0; }
+  bool seen1 = false;
+  for (int j = 0; j < d->n_taps; ++j) {
+    int r = d->tap_phase[j];
+    UNET_REQUIRE(r >= 0 && r < d->up, "conv: tap %d has phase %d but up=%d", j, r, d->up);
+    UNET_REQUIRE(r >= prev, "conv: taps must be grouped by phase (phase 0 first)");
+    if (r == 1 && !seen1) { ph->pbeg[1] = j; seen1 = true; }
+    prev = r;
+    UNET_REQUIRE(d->tap_off[j] > -4096 && d->tap_off[j] < 4096, "conv: tap offset %d too large", d->tap_off[j]);
+  }
+  for (int r = 0; r < 2; ++r) {
+    int b = ph->pbeg[r], e = ph->pbeg[r + 1];
+    if (e > b) {
+      int lo = d->tap_off[b], hi = d->tap_off[b];
+      for (int j = b; j < e; ++j) { lo = d->tap_off[j] < lo ? d->tap_off[j] : lo; hi = d->tap_off[j] > hi ? d->tap_off[j] : hi; }
+      ph->omin[r] = lo; ph->omax[r] = hi;
+    }
+    // m such that up*m + r < l_out
+    ph->mcount[r] = r < d->up ? (d->l_out - r + d->up - 1) / d->up : 0;
+    if (ph->mcount[r] < 0) ph->mcount[r] = 0;
+  }
+  return 0;
+}
+
+int kchunks(int dtype, int c) { int kc = dtype == UNET_F32 ? 32 : 64; return (c + kc - 1) / kc; }
+int esize(int dtype) { return dtype == UNET_F32 ? 4 : 2; }
+bool vec_ok(const void* p, long long ld, long long ns, int es) {
+  return aligned16(p) && (ld * es) % 16 == 0 && (ns * es) % 16 == 0;
+}
+bool vec8_ok(const void* p, long long ld, long long ns, int es) {  // 4-element vectors
+  const int b = 4 * es;
+  return (reinterpret_cast<uintptr_t>(p) % b) == 0 && (ld * es) % b == 0 && (ns * es) % b == 0;
+}
+
+template <bool F32, int BN>
+int launch_fwd(const ConvK& k, int rmax, hipStream_t st) {
+  static bool attr_set = false;
+  const size_t lds = 2 * WTILE_BYTES + (size_t)rmax * 128;
+  UNET_REQUIRE(lds <= 160 * 1024, "conv: tap span needs %zu bytes of LDS (max 163840)", lds);
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<F32, BN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    UNET_REQUIRE(e == hipSuccess, "conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const long long blocks = (long long)k.mtiles * k.n * (k.ptiles[0] + k.ptiles[1]);
+  UNET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv: grid of %lld blocks", blocks);
+  hipLaunchKernelGGL((conv_fwd_kernel<F32, BN>), dim3((unsigned)blocks), dim3(THREADS), lds, st, k);
+  UNET_LAUNCH_CHECK("conv_fwd");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t unet_conv1d_packed_bytes(int32_t dtype, int32_t n_taps, int32_t rows, int32_t c1, int32_t c2) {
+  const int kct = kchunks(dtype, c1) + (c2 > 0 ? kchunks(dtype, c2) : 0);
+  return (size_t)n_taps * cdiv(rows, BM) * kct * WTILE_BYTES;
+}
+
+extern "C" int unet_conv1d_pack(int32_t dtype, const float* w, int64_t tap_stride, int64_t row_stride,
+                                int64_t col_stride, int32_t n_taps, const int32_t* tap_src_host,
+                                int32_t row_lo, int32_t rows, int32_t col_lo, int32_t c1, int32_t c2,
+                                void* packed, void* stream) {
+  UNET_REQUIRE(dtype == UNET_BF16 || dtype == UNET_F32, "pack: bad dtype %d", dtype);
+  UNET_REQUIRE(n_taps > 0 && n_taps <= UNET_MAX_TAPS && rows > 0 && c1 > 0 && c2 >= 0, "pack: bad sizes");
+  UNET_REQUIRE(w && packed && aligned16(packed), "pack: null or misaligned pointer");
+  PackK k;
+  k.w = w; k.ts = tap_stride; k.rs = row_stride; k.cs = col_stride;
+  k.n_taps = n_taps; k.row_lo = row_lo; k.rows = rows; k.col_lo = col_lo; k.c1 = c1; k.c2 = c2;
+  k.kc1 = kchunks(dtype, c1); k.kctot = k.kc1 + (c2 > 0 ? kchunks(dtype, c2) : 0);
+  k.mtiles = cdiv(rows, BM);
+  for (int j = 0; j < n_taps; ++j) k.tap_src[j] = tap_src_host ? tap_src_host[j] : j;
+  k.out = static_cast<char*>(packed);
+  const long long total = (long long)n_taps * k.mtiles * k.kctot * 1024;
+  const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == UNET_F32) hipLaunchKernelGGL(conv_pack_kernel<true>, dim3(blocks), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL(conv_pack_kernel<false>, dim3(blocks), dim3(256), 0, st, k);
+  UNET_LAUNCH_CHECK("conv_pack");
+  return 0;
+}
+
+extern "C" int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void* x2, const void* w_packed,
+                               const float* bias, const void* res, void* y, void* stream) {
+  UNET_REQUIRE(d && x1 && w_packed && y, "conv_fwd: null pointer");
+  Phases ph;
+  if (analyse(d, &ph)) return -1;
+  UNET_REQUIRE(d->c2 == 0 || x2, "conv_fwd: c2>0 but x2 is null");
+  UNET_REQUIRE(aligned16(w_packed), "conv_fwd: packed weights must be 16-byte aligned");
+  const int es = esize(d->dtype);
+  ConvK k;
+  k.x1 = static_cast<const char*>(x1); k.x2 = static_cast<const char*>(x2);
+  k.wp = static_cast<const char*>(w_packed); k.bias = bias; k.res = static_cast<const char*>(res);
+  k.y = static_cast<char*>(y);
+  k.x1_ns = d->x1_ns; k.x2_ns = d->x2_ns; k.y_ns = d->y_ns; k.res_ns = d->res_ns;
+  k.x1_ld = d->x1_ld; k.x2_ld = d->x2_ld; k.y_ld = d->y_ld; k.res_ld = d->res_ld;
+  k.c1 = d->c1; k.c2 = d->c2;
+  k.kc1 = kchunks(d->dtype, d->c1); k.kctot = k.kc1 + (d->c2 > 0 ? kchunks(d->dtype, d->c2) : 0);
+  k.l_in = d->l_in; k.l_out = d->l_out; k.c_out = d->c_out; k.n = d->n;
+  k.stride = d->stride; k.up = d->up; k.act = d->act;
+  k.mtiles = cdiv(d->c_out, BM);
+  for (int r = 0; r < 3; ++r) k.pbeg[r] = ph.pbeg[r];
+  for (int j = 0; j < UNET_MAX_TAPS; ++j) k.tap_off[j] = j < d->n_taps ? d->tap_off[j] : 0;
+  k.x1_vec = vec_ok(x1, d->x1_ld, d->x1_ns, es);
+  k.x2_vec = x2 ? vec_ok(x2, d->x2_ld, d->x2_ns, es) : 0;
+  k.y_vec = vec8_ok(y, d->y_ld, d->y_ns, es);
+  k.res_vec = res ? vec8_ok(res, d->res_ld, d->res_ns, es) : 0;
+  // tile width: 128 positions unless the halo tile would not leave room for two blocks per CU
+  int span = 0;
+  for (int r = 0; r < 2; ++r) {
+    k.omin[r] = ph.omin[r]; k.omax[r] = ph.omax[r]; k.mcount[r] = ph.mcount[r];
+    int s = ph.omax[r] - ph.omin[r] + 1;
+    span = s > span ? s : span;
+  }
+  int bn = 128;
+  {
+    const char* env = getenv("UNET_CONV_BN");
+    if (env && atoi(env) == 64) bn = 64;
+    else if (!env) {
+      const size_t lds128 = 2 * WTILE_BYTES + (size_t)(d->stride * 127 + span) * 128;
+      if (lds128 > 80 * 1024) bn = 64;
+    }
+  }
+  for (int r = 0; r < 2; ++r) k.ptiles[r] = (r < d->up) ? cdiv(ph.mcount[r], bn) : 0;
+  const int rmax = d->stride * (bn - 1) + span;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (d->dtype == UNET_F32) return bn == 128 ? launch_fwd<true, 128>(k, rmax, st) : launch_fwd<true, 64>(k, rmax, st);
+  return bn == 128 ? launch_fwd<false, 128>(k, rmax, st) : launch_fwd<false, 64>(k, rmax, st);
+}
+
+namespace {
+int wgrad_splits(const UnetConvDesc* d, const Phases& ph) {
+  const int bkp = d->dtype == UNET_F32 ? 32 : 64;
+  const int kt = cdiv(d->c1, 128) + (d->c2 > 0 ? cdiv(d->c2, 128) : 0);
+  const long long tiles = (long long)d->n_taps * cdiv(d->c_out, BM) * kt;
+  int mc = ph.mcount[0] > ph.mcount[1] ? ph.mcount[0] : ph.mcount[1];
+  long long items = (long long)d->n * cdiv(mc, bkp);
+  long long s = (2048 + tiles - 1) / tiles;
+  if (s > 64) s = 64;
+  if (s > items) s = items;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+}  // namespace
+
+extern "C" size_t unet_conv1d_wgrad_workspace_bytes(const UnetConvDesc* d) {
+  Phases ph;
+  if (!d || analyse(d, &ph)) return 0;
+  return (size_t)wgrad_splits(d, ph) * d->n_taps * d->c_out * (d->c1 + d->c2) * sizeof(float);
+}
+
+extern "C" int unet_conv1d_wgrad(const UnetConvDesc* d, const void* x1, const void* x2, const void* dy,
+                                 float* dw, void* workspace, size_t ws_bytes, void* stream) {
+  UNET_REQUIRE(d && x1 && dy && dw, "conv_wgrad: null pointer");
+  Phases ph;
+  if (analyse(d, &ph)) return -1;
+  UNET_REQUIRE(d->n_taps > 0, "conv_wgrad: no taps");
+  UNET_REQUIRE(d->c2 == 0 || x2, "conv_wgrad: c2>0 but x2 is null");
+  const int splits = wgrad_splits(d, ph);
+  const size_t need = (size_t)splits * d->n_taps * d->c_out * (d->c1 + d->c2) * sizeof(float);
+  UNET_REQUIRE(workspace && ws_bytes >= need, "conv_wgrad: workspace %zu bytes < %zu needed", ws_bytes, need);
+  const int es = esize(d->dtype);
+  WgK k;
+  k.x1 = static_cast<const char*>(x1); k.x2 = static_cast<const char*>(x2); k.dy = static_cast<const char*>(dy);
+  k.slab = static_cast<float*>(workspace);
+  k.x1_ns = d->x1_ns; k.x2_ns = d->x2_ns; k.dy_ns = d->y_ns;
+  k.x1_ld = d->x1_ld; k.x2_ld = d->x2_ld; k.dy_ld = d->y_ld;
+  k.c1 = d->c1; k.c2 = d->c2; k.kt1 = cdiv(d->c1, 128); k.kttot = k.kt1 + (d->c2 > 0 ? cdiv(d->c2, 128) : 0);
+  k.l_in = d->l_in; k.c_out = d->c_out; k.n = d->n; k.stride = d->stride; k.up = d->up;
+  k.mtiles = cdiv(d->c_out, BM); k.n_taps = d->n_taps; k.splits = splits;
+  k.mcount[0] = ph.mcount[0]; k.mcount[1] = ph.mcount[1];
+  k.x1_vec = vec_ok(x1, d->x1_ld, d->x1_ns, es);
+  k.x2_vec = x2 ? vec_ok(x2, d->x2_ld, d->x2_ns, es) : 0;
+  k.dy_vec = vec_ok(dy, d->y_ld, d->y_ns, es);
+  for (int j = 0; j < UNET_MAX_TAPS; ++j) {
+    k.tap_off[j] = j < d->n_taps ? d->tap_off[j] : 0;
+    k.tap_phase[j] = j < d->n_taps ? d->tap_phase[j] : 0;
+  }
+  const long long blocks = (long long)k.mtiles * k.kttot * splits * d->n_taps;
+  UNET_REQUIRE(blocks < (1ll << 31), "conv_wgrad: grid too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (d->dtype == UNET_F32) hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3((unsigned)blocks), dim3(THREADS), 0, st, k);
+  else hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3((unsigned)blocks), dim3(THREADS), 0, st, k);
+  UNET_LAUNCH_CHECK("conv_wgrad");
+  const long long count = (long long)d->n_taps * d->c_out * (d->c1 + d->c2);
+  int rb = (int)((count + 255) / 256 > 4096 ? 4096 : (count + 255) / 256);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, st, k.slab, dw, count, splits);
+  UNET_LAUNCH_CHECK("slab_reduce");
+  return 0;
+}

@@ -1,0 +1,738 @@
+// Channels-last streaming kernels (HBM-bound): per-(window,channel) coefficient broadcast,
+// activations, and per-(window,channel) reductions over rows.
+//
+// Thread mapping: channels are the contiguous axis, so a thread owns ONE vector column
+// (V = 16 bytes of channels) and walks rows; consecutive lanes read consecutive 16-byte vectors
+// (full-line coalescing), per-channel partial sums stay in registers for the whole walk and are
+// combined across the block's row lanes through LDS once.  Partial sums go to
+// [n][part][c] fp32 (deterministic; no float atomics) and the host adds the parts.
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS_PER_PART = 128;
+constexpr int THREADS = 256;
+
+template <class OP>
+__global__ __launch_bounds__(THREADS) void rowstream_kernel(OP op, int rows, int c, int parts) {
+  constexpr int V = OP::V;
+  constexpr int NR = OP::NRED;
+  __shared__ float red_s[(NR > 0 ? NR : 1) * V * THREADS];
+  const int n = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
+  const int cv = c / V;
+  const int cvb = cv < THREADS ? cv : THREADS;
+  const int RL = THREADS / cvb;
+  const int rl = tid / cvb, cgl = tid - rl * cvb;
+  const int r_begin = part * ROWS_PER_PART;
+  const int r_end = rows < r_begin + ROWS_PER_PART ? rows : r_begin + ROWS_PER_PART;
+  for (int cb = 0; cb < cv; cb += cvb) {
+    const int cg = cb + cgl;
+    const bool active = rl < RL && cg < cv;
+    float acc[NR > 0 ? NR : 1][V];
+#pragma unroll
+    for (int k = 0; k < (NR > 0 ? NR : 1); ++k)
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[k][v] = 0.f;
+    if (active) {
+      typename OP::State st;
+      op.init(st, n, cg * V, c);
+      for (int r = r_begin + rl; r < r_end; r += RL)
+        op.row(st, ((long long)n * rows + r) * c + cg * V, acc);
+    }
+    if constexpr (NR > 0) {
+#pragma unroll
+      for (int k = 0; k < NR; ++k)
+#pragma unroll
+        for (int v = 0; v < V; ++v) red_s[(k * V + v) * THREADS + tid] = acc[k][v];
+      __syncthreads();
+      if (rl == 0 && active) {
+        float sums[NR][V];
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            float s = 0.f;
+            for (int j = 0; j < RL; ++j) s += red_s[(k * V + v) * THREADS + j * cvb + cgl];
+            sums[k][v] = s;
+          }
+        op.write_part(((long long)n * parts + part) * c + cg * V, sums);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <typename T, int V_> struct OpBase {
+  static constexpr int V = V_;
+  __device__ static __forceinline__ void ldc(const float* p, float (&f)[V_]) {
+#pragma unroll
+    for (int i = 0; i < V_; ++i) f[i] = p[i];
+  }
+  __device__ static __forceinline__ void stc(float* p, const float (&f)[V_]) {
+#pragma unroll
+    for (int i = 0; i < V_; ++i) p[i] = f[i];
+  }
+};
+
+// ---- s1 = sum y, s2 = sum y^2 ------------------------------------------------------------------
+template <typename T, int V_> struct RowStatsOp : OpBase<T, V_> {
+  static constexpr int NRED = 2;
+  const T* y; float* s1; float* s2;
+  struct State {};
+  __device__ void init(State&, int, int, int) const {}
+  __device__ void row(State&, long long e, float (&acc)[2][V_]) const {
+    float f[V_];
+    VecIO<T, V_>::load(y + e, f);
+#pragma unroll
+    for (int i = 0; i < V_; ++i) { acc[0][i] += f[i]; acc[1][i] += f[i] * f[i]; }
+  }
+  __device__ void write_part(long long e, const float (&s)[2][V_]) const {
+    this->stc(s1 + e, s[0]); this->stc(s2 + e, s[1]);
+  }
+};
+
+// ---- column sum --------------------------------------------------------------------------------
+template <typename T, int V_> struct ColSumOp : OpBase<T, V_> {
+  static constexpr int NRED = 1;
+  const T* x; float* out;
+  struct State {};
+  __device__ void init(State&, int, int, int) const {}
+  __device__ void row(State&, long long e, float (&acc)[1][V_]) const {
+    float f[V_];
+    VecIO<T, V_>::load(x + e, f);
+#pragma unroll
+    for (int i = 0; i < V_; ++i) acc[0][i] += f[i];
+  }
+  __device__ void write_part(long long e, const float (&s)[1][V_]) const { this->stc(out + e, s[0]); }
+};
+
+// ---- z = act(a*y+b), pool = sum z -----------------------------------------------------------------
+template <typename T, int V_, bool POOL> struct AffineActFwdOp : OpBase<T, V_> {
+  static constexpr int NRED = POOL ? 1 : 0;
+  const T* y; T* z; const float* a; const float* b; float* pool; int act;
+  struct State { float a[V_], b[V_]; };
+  __device__ void init(State& s, int n, int c0, int c) const {
+    this->ldc(a + (long long)n * c + c0, s.a); this->ldc(b + (long long)n * c + c0, s.b);
+  }
+  __device__ void row(State& s, long long e, float (&acc)[POOL ? 1 : 1][V_]) const {
+    float f[V_];
+    VecIO<T, V_>::load(y + e, f);
+#pragma unroll
+    for (int i = 0; i < V_; ++i) {
+      f[i] = act_fwd(act, s.a[i] * f[i] + s.b[i]);
+      if (POOL) acc[0][i] += f[i];
+    }
+    VecIO<T, V_>::store(z + e, f);
+  }
+  __device__ void write_part(long long e, const float (&s)[1][V_]) const { this->stc(pool + e, s[0]); }
+};
+
+// ---- backward of the above ---------------------------------------------------------------------
+template <typename T, int V_, bool APPLY> struct AffineActBwdOp : OpBase<T, V_> {
+  static constexpr int NRED = APPLY ? 0 : 2;
+  const T* y; const T* dz; const float* dpool; const float* a; const float* b; int act;
+  float* g1; float* g2;                       // reduce
+  const float* ca; const float* cb; const float* cc; T* dy;  // apply
+  struct State { float a[V_], b[V_], dp[V_], ca[V_], cb[V_], cc[V_]; };
+  __device__ void init(State& s, int n, int c0, int c) const {
+    const long long o = (long long)n * c + c0;
+    this->ldc(a + o, s.a); this->ldc(b + o, s.b);
+    if (dpool) this->ldc(dpool + o, s.dp);
+    else {
+#pragma unroll
+      for (int i = 0; i < V_; ++i) s.dp[i] = 0.f;
+    }
+    if (APPLY) { this->ldc(ca + o, s.ca); this->ldc(cb + o, s.cb); this->ldc(cc + o, s.cc); }
+  }
+  __device__ void row(State& s, long long e, float (&acc)[APPLY ? 1 : 2][V_]) const {
+    float fy[V_], fd[V_];
+    VecIO<T, V_>::load(y + e, fy);
+    VecIO<T, V_>::load(dz + e, fd);
+    float out[V_];
+#pragma unroll
+    for (int i = 0; i < V_; ++i) {
+      const float g = (fd[i] + s.dp[i]) * act_bwd(act, s.a[i] * fy[i] + s.b[i]);
+      if (APPLY) out[i] = s.ca[i] * g + s.cb[i] * fy[i] + s.cc[i];
+      else { acc[0][i] += g; acc[1][i] += g * fy[i]; }
+    }
+    if (APPLY) VecIO<T, V_>::store(dy + e, out);
+  }
+  __device__ void write_part(long long e, const float (&s)[2][V_]) const {
+    this->stc(g1 + e, s[0]); this->stc(g2 + e, s[1]);
+  }
+};
+
+// ---- out = x*s ;  dx = dout*s, ds = sum dout*x ----------------------------------------------------
+template <typename T, int V_> struct ScaleFwdOp : OpBase<T, V_> {
+  static constexpr int NRED = 0;
+  const T* x; T* out; const float* s;
+  struct State { float s[V_]; };
+  __device__ void init(State& st, int n, int c0, int c) const { this->ldc(s + (long long)n * c + c0, st.s); }
+  __device__ void row(State& st, long long e, float (&)[1][V_]) const {
+    float f[V_];
+    VecIO<T, V_>::load(x + e, f);
+#pragma unroll
+    for (int i = 0; i < V_; ++i) f[i] *= st.s[i];
+    VecIO<T, V_>::store(out + e, f);
+  }
+  __device__ void write_part(long long, const float (&)[1][V_]) const {}
+};
+template <typename T, int V_> struct ScaleBwdOp : OpBase<T, V_> {
+  static constexpr int NRED = 1;
+  const T* x; const T* dout; T* dx; const float* s; float* ds;
+  struct State { float s[V_]; };
+  __device__ void init(State& st, int n, int c0, int c) const { this->ldc(s + (long long)n * c + c0, st.s); }
+  __device__ void row(State& st, long long e, float (&acc)[1][V_]) const {
+    float fx[V_], fd[V_];
+    VecIO<T, V_>::load(x + e, fx);
+    VecIO<T, V_>::load(dout + e, fd);
+#pragma unroll
+    for (int i = 0; i < V_; ++i) { acc[0][i] += fd[i] * fx[i]; fd[i] *= st.s[i]; }
+    VecIO<T, V_>::store(dx + e, fd);
+  }
+  __device__ void write_part(long long e, const float (&sm)[1][V_]) const { this->stc(ds + e, sm[0]); }
+};
+
+// ---- out = res + g*o ;  d_o = g*dout, dg = sum dout*o ----------------------------------------------
+template <typename T, int V_> struct GatedAddFwdOp : OpBase<T, V_> {
+  static constexpr int NRED = 0;
+  const T* res; const T* o; T* out; const float* g;
+  struct State { float g[V_]; };
+  __device__ void init(State& st, int n, int c0, int c) const { this->ldc(g + (long long)n * c + c0, st.g); }
+  __device__ void row(State& st, long long e, float (&)[1][V_]) const {
+    float fr[V_], fo[V_];
+    VecIO<T, V_>::load(res + e, fr);
+    VecIO<T, V_>::load(o + e, fo);
+#pragma unroll
+    for (int i = 0; i < V_; ++i) fr[i] += st.g[i] * fo[i];
+    VecIO<T, V_>::store(out + e, fr);
+  }
+  __device__ void write_part(long long, const float (&)[1][V_]) const {}
+};
+template <typename T, int V_> struct GatedAddBwdOp : OpBase<T, V_> {
+  static constexpr int NRED = 1;
+  const T* o; const T* dout; T* d_o; const float* g; float* dg;
+  struct State { float g[V_]; };
+  __device__ void init(State& st, int n, int c0, int c) const { this->ldc(g + (long long)n * c + c0, st.g); }
+  __device__ void row(State& st, long long e, float (&acc)[1][V_]) const {
+    float fo[V_], fd[V_];
+    VecIO<T, V_>::load(o + e, fo);
+    VecIO<T, V_>::load(dout + e, fd);
+#pragma unroll
+    for (int i = 0; i < V_; ++i) { acc[0][i] += fd[i] * fo[i]; fd[i] *= st.g[i]; }
+    VecIO<T, V_>::store(d_o + e, fd);
+  }
+  __device__ void write_part(long long e, const float (&sm)[1][V_]) const { this->stc(dg + e, sm[0]); }
+};
+
+template <class OP>
+int launch_rows(const OP& op, int n, int rows, int c, hipStream_t st, const char* what) {
+  const int parts = cdiv(rows, ROWS_PER_PART);
+  hipLaunchKernelGGL(rowstream_kernel<OP>, dim3(parts, n), dim3(THREADS), 0, st, op, rows, c, parts);
+  UNET_LAUNCH_CHECK(what);
+  return 0;
+}
+
+// vector width usable for a set of pointers: 16 bytes when channels and bases allow, else scalar
+template <typename T> bool can_vec(int c, std::initializer_list<const void*> ptrs) {
+  constexpr int V = 16 / (int)sizeof(T);
+  if (c % V) return false;
+  for (const void* p : ptrs)
+    if (p && !aligned16(p)) return false;
+  return true;
+}
+
+#define DISPATCH_ROWS(dtype, c, ptrs, ...)                                        \
+  do {                                                                              \
+    if ((dtype) == UNET_F32) {                                                      \
+      typedef float T;                                                              \
+      if (can_vec<T>(c, ptrs)) { constexpr int V = 4; __VA_ARGS__ } else { constexpr int V = 1; __VA_ARGS__ } \
+    } else if ((dtype) == UNET_BF16) {                                              \
+      typedef __bf16 T;                                                             \
+      if (can_vec<T>(c, ptrs)) { constexpr int V = 8; __VA_ARGS__ } else { constexpr int V = 1; __VA_ARGS__ } \
+    } else {                                                                        \
+      unet_set_error("bad dtype %d", (int)(dtype));                                 \
+      return -1;                                                                    \
+    }                                                                               \
+  } while (0)
+
+#define PL(...) std::initializer_list<const void*>{__VA_ARGS__}
+
+int check_dims(int n, int rows, int c, const char* what) {
+  UNET_REQUIRE(n > 0 && rows > 0 && c > 0, "%s: non-positive dims n=%d rows=%d c=%d", what, n, rows, c);
+  UNET_REQUIRE(n <= 65535, "%s: n=%d exceeds grid.y limit", what, n);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FiLM channel softmax: one wave per row, lanes stride over channel vectors of 4.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int V, int NV>
+__global__ __launch_bounds__(THREADS) void film_softmax_fwd_kernel(const T* q, const float* kk, const float* vv,
+                                                                    T* h, int rows, int c) {
+  const int n = blockIdx.y, part = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cv = c / V;
+  float k[NV][V], v[NV][V];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int cg = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      k[i][e] = cg < cv ? kk[(long long)n * c + cg * V + e] : 0.f;
+      v[i][e] = cg < cv ? vv[(long long)n * c + cg * V + e] : 0.f;
+    }
+  }
+  const int r_begin = part * ROWS_PER_PART;
+  const int r_end = rows < r_begin + ROWS_PER_PART ? rows : r_begin + ROWS_PER_PART;
+  for (int r = r_begin + wave; r < r_end; r += THREADS / 64) {
+    const long long base = ((long long)n * rows + r) * c;
+    float s[NV][V];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int cg = lane + 64 * i;
+      if (cg < cv) {
+        VecIO<T, V>::load(q + base + cg * V, s[i]);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { s[i][e] *= k[i][e]; mx = fmaxf(mx, s[i][e]); }
+      }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int cg = lane + 64 * i;
+      if (cg < cv) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { s[i][e] = __expf(s[i][e] - mx); sum += s[i][e]; }
+      }
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int cg = lane + 64 * i;
+      if (cg < cv) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[i][e] = s[i][e] * inv * v[i][e];
+        VecIO<T, V>::store(h + base + cg * V, s[i]);
+      }
+    }
+  }
+}
+
+template <typename T, int V, int NV>
+__global__ __launch_bounds__(THREADS) void film_softmax_bwd_kernel(const T* q, const T* dh, const float* kk,
+                                                                    const float* vv, T* dq, float* dkk_part,
+                                                                    float* dv_part, int rows, int c, int parts) {
+  __shared__ float red_s[2][THREADS / 64][64 * NV * V];
+  const int n = blockIdx.y, part = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cv = c / V;
+  float k[NV][V], v[NV][V], akk[NV][V], av[NV][V];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int cg = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      k[i][e] = cg < cv ? kk[(long long)n * c + cg * V + e] : 0.f;
+      v[i][e] = cg < cv ? vv[(long long)n * c + cg * V + e] : 0.f;
+      akk[i][e] = 0.f; av[i][e] = 0.f;
+    }
+  }
+  const int r_begin = part * ROWS_PER_PART;
+  const int r_end = rows < r_begin + ROWS_PER_PART ? rows : r_begin + ROWS_PER_PART;
+  for (int r = r_begin + wave; r < r_end; r += THREADS / 64) {
+    const long long base = ((long long)n * rows + r) * c;
+    float s[NV][V], qv[NV][V], g[NV][V];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int cg = lane + 64 * i;
+      if (cg < cv) {
+        VecIO<T, V>::load(q + base + cg * V, qv[i]);
+        VecIO<T, V>::load(dh + base + cg * V, g[i]);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { s[i][e] = qv[i][e] * k[i][e]; mx = fmaxf(mx, s[i][e]); }
+      }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int cg = lane + 64 * i;
+      if (cg < cv) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { s[i][e] = __expf(s[i][e] - mx); sum += s[i][e]; }
+      }
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    float dot = 0.f;  // sum_c a * da,  da = dh * v
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int cg = lane + 64 * i;
+      if (cg < cv) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          s[i][e] *= inv;                       // a
+          av[i][e] += g[i][e] * s[i][e];        // dv += dh * a
+          g[i][e] *= v[i][e];                   // da
+          dot += s[i][e] * g[i][e];
+        }
+      }
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int cg = lane + 64 * i;
+      if (cg < cv) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float ds = s[i][e] * (g[i][e] - dot);  // d(q*kk)
+          akk[i][e] += ds * qv[i][e];
+          g[i][e] = ds * k[i][e];
+        }
+        VecIO<T, V>::store(dq + base + cg * V, g[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      red_s[0][wave][(i * V + e) * 64 + lane] = akk[i][e];
+      red_s[1][wave][(i * V + e) * 64 + lane] = av[i][e];
+    }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int cg = lane + 64 * i;
+      if (cg < cv) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          float a0 = 0.f, a1 = 0.f;
+          for (int w = 0; w < THREADS / 64; ++w) {
+            a0 += red_s[0][w][(i * V + e) * 64 + lane];
+            a1 += red_s[1][w][(i * V + e) * 64 + lane];
+          }
+          const long long o = ((long long)n * parts + part) * c + cg * V + e;
+          dkk_part[o] = a0; dv_part[o] = a1;
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int V>
+int film_dispatch(bool bwd, const void* q, const void* dh, const float* kk, const float* v, void* out,
+                  float* dkk, float* dv, int n, int rows, int c, hipStream_t st) {
+  const int cv = c / V;
+  const int nv = cdiv(cv, 64);
+  const int parts = cdiv(rows, ROWS_PER_PART);
+  dim3 grid(parts, n), blk(THREADS);
+#define FILM_CASE(NVV)                                                                                  \
+  if (nv <= NVV) {                                                                                      \
+    if (bwd)                                                                                            \
+      hipLaunchKernelGGL((film_softmax_bwd_kernel<T, V, NVV>), grid, blk, 0, st, (const T*)q, (const T*)dh, kk, \
+                         v, (T*)out, dkk, dv, rows, c, parts);                                          \
+    else                                                                                                \
+      hipLaunchKernelGGL((film_softmax_fwd_kernel<T, V, NVV>), grid, blk, 0, st, (const T*)q, kk, v, (T*)out, rows, c); \
+    UNET_LAUNCH_CHECK("film_softmax");                                                                  \
+    return 0;                                                                                           \
+  }
+  FILM_CASE(1) FILM_CASE(2) FILM_CASE(4) FILM_CASE(8)
+  if (V == 4) { FILM_CASE(16) }
+#undef FILM_CASE
+  unet_set_error("film_softmax: %d channels unsupported (max %d)", c, V == 4 ? 4096 : 512);
+  return -1;
+}
+
+int film_entry(bool bwd, int dtype, const void* q, const void* dh, const float* kk, const float* v, void* out,
+               float* dkk, float* dv, int n, int rows, int c, void* stream) {
+  if (check_dims(n, rows, c, "film_softmax")) return -1;
+  UNET_REQUIRE(q && kk && v && out && (!bwd || (dh && dkk && dv)), "film_softmax: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == UNET_F32) {
+    const bool vec = c % 4 == 0 && aligned16(q) && aligned16(out) && (!dh || aligned16(dh));
+    return vec ? film_dispatch<float, 4>(bwd, q, dh, kk, v, out, dkk, dv, n, rows, c, st)
+               : film_dispatch<float, 1>(bwd, q, dh, kk, v, out, dkk, dv, n, rows, c, st);
+  }
+  if (dtype == UNET_BF16) {
+    const bool vec = c % 4 == 0 && ((uintptr_t)q % 8 == 0) && ((uintptr_t)out % 8 == 0) && (!dh || (uintptr_t)dh % 8 == 0);
+    return vec ? film_dispatch<__bf16, 4>(bwd, q, dh, kk, v, out, dkk, dv, n, rows, c, st)
+               : film_dispatch<__bf16, 1>(bwd, q, dh, kk, v, out, dkk, dv, n, rows, c, st);
+  }
+  unet_set_error("film_softmax: bad dtype %d", dtype);
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout change at the model boundary (tiled transpose through LDS, both sides coalesced)
+//   NCL->NLC:  y[n][t][c] = (x[n][c][t] - sub[n][c]) * mul[n][c]          (z-score apply)
+//   NLC->NCL:  y[n][c][t] = ga[n][c]*x[n][t][c] + gb[n][c]*x2[n][t][c] + be[n][c]
+// ---------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(THREADS) void ncl_to_nlc_kernel(const TI* x, TO* y, const float* sub, const float* mul,
+                                                              int c, int t) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  for (int i = ly; i < 64; i += 4) {
+    const int cc = c0 + i, tt = t0 + lx;
+    float v = 0.f;
+    if (cc < c && tt < t) {
+      v = to_f32(x[((long long)n * c + cc) * t + tt]);
+      if (sub) v = (v - sub[(long long)n * c + cc]) * mul[(long long)n * c + cc];
+    }
+    tile[i][lx] = v;
+  }
+  __syncthreads();
+  for (int i = ly; i < 64; i += 4) {
+    const int tt = t0 + i, cc = c0 + lx;
+    if (cc < c && tt < t) y[((long long)n * t + tt) * c + cc] = from_f32<TO>(tile[lx][i]);
+  }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(THREADS) void nlc_to_ncl_kernel(const TI* x, const TI* x2, TO* y, const float* ga,
+                                                              const float* gb, const float* be, int c, int t) {
+  __shared__ float tile[64][65];
+  const int n = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  for (int i = ly; i < 64; i += 4) {
+    const int tt = t0 + i, cc = c0 + lx;
+    float v = 0.f;
+    if (cc < c && tt < t) {
+      const long long e = ((long long)n * t + tt) * c + cc;
+      v = to_f32(x[e]);
+      if (ga) v *= ga[(long long)n * c + cc];
+      if (x2) v += gb[(long long)n * c + cc] * to_f32(x2[e]);
+      if (be) v += be[(long long)n * c + cc];
+    }
+    tile[i][lx] = v;
+  }
+  __syncthreads();
+  for (int i = ly; i < 64; i += 4) {
+    const int cc = c0 + i, tt = t0 + lx;
+    if (cc < c && tt < t) y[((long long)n * c + cc) * t + tt] = from_f32<TO>(tile[lx][i]);
+  }
+}
+
+// per-(window,channel) mean and 1/(std_unbiased + eps) over the contiguous T axis of an NCL tensor
+template <typename TI>
+__global__ __launch_bounds__(THREADS) void ncl_rowmoments_kernel(const TI* x, float* mean, float* rstd, int t, float eps) {
+  __shared__ float red[THREADS / 64];
+  __shared__ float mean_s;
+  const long long row = blockIdx.x;
+  const TI* p = x + row * t;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < t; i += THREADS) s += to_f32(p[i]);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) mean_s = (red[0] + red[1] + red[2] + red[3]) / (float)t;
+  __syncthreads();
+  const float m = mean_s;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < t; i += THREADS) { const float d = to_f32(p[i]) - m; q += d * d; }
+  q = wave_sum(q);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float var = (red[0] + red[1] + red[2] + red[3]) / (float)(t > 1 ? t - 1 : 1);
+    mean[row] = m;
+    rstd[row] = 1.f / (sqrtf(var) + eps);
+  }
+}
+
+template <typename TI>
+int transpose_in(int dtype, const void* x, void* y, const float* sub, const float* mul, int n, int c, int t, hipStream_t st) {
+  dim3 grid(cdiv(t, 64), cdiv(c, 64), n), blk(THREADS);
+  if (dtype == UNET_F32) hipLaunchKernelGGL((ncl_to_nlc_kernel<TI, float>), grid, blk, 0, st, (const TI*)x, (float*)y, sub, mul, c, t);
+  else hipLaunchKernelGGL((ncl_to_nlc_kernel<TI, __bf16>), grid, blk, 0, st, (const TI*)x, (__bf16*)y, sub, mul, c, t);
+  UNET_LAUNCH_CHECK("ncl_to_nlc");
+  return 0;
+}
+template <typename TI>
+int transpose_out(int out_dtype, const void* x, const void* x2, void* y, const float* ga, const float* gb,
+                  const float* be, int n, int c, int t, hipStream_t st) {
+  dim3 grid(cdiv(t, 64), cdiv(c, 64), n), blk(THREADS);
+  if (out_dtype == UNET_F32) hipLaunchKernelGGL((nlc_to_ncl_kernel<TI, float>), grid, blk, 0, st, (const TI*)x, (const TI*)x2, (float*)y, ga, gb, be, c, t);
+  else hipLaunchKernelGGL((nlc_to_ncl_kernel<TI, __bf16>), grid, blk, 0, st, (const TI*)x, (const TI*)x2, (__bf16*)y, ga, gb, be, c, t);
+  UNET_LAUNCH_CHECK("nlc_to_ncl");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int32_t unet_parts(int32_t rows) { return cdiv(rows, ROWS_PER_PART); }
+
+extern "C" int unet_rowstats(int32_t dtype, const void* y, float* s1_part, float* s2_part, int32_t n,
+                             int32_t rows, int32_t c, void* stream) {
+  if (check_dims(n, rows, c, "rowstats")) return -1;
+  UNET_REQUIRE(y && s1_part && s2_part, "rowstats: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH_ROWS(dtype, c, PL(y), {
+    RowStatsOp<T, V> op; op.y = (const T*)y; op.s1 = s1_part; op.s2 = s2_part;
+    return launch_rows(op, n, rows, c, st, "rowstats");
+  });
+  return 0;
+}
+
+extern "C" int unet_colsum(int32_t dtype, const void* x, float* out_part, int32_t n, int32_t rows, int32_t c,
+                           void* stream) {
+  if (check_dims(n, rows, c, "colsum")) return -1;
+  UNET_REQUIRE(x && out_part, "colsum: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH_ROWS(dtype, c, PL(x), {
+    ColSumOp<T, V> op; op.x = (const T*)x; op.out = out_part;
+    return launch_rows(op, n, rows, c, st, "colsum");
+  });
+  return 0;
+}
+
+extern "C" int unet_affine_act_fwd(int32_t dtype, const void* y, const float* a, const float* b, int32_t act,
+                                   void* z, float* pool_part, int32_t n, int32_t rows, int32_t c, void* stream) {
+  if (check_dims(n, rows, c, "affine_act_fwd")) return -1;
+  UNET_REQUIRE(y && a && b && z, "affine_act_fwd: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (pool_part) {
+    DISPATCH_ROWS(dtype, c, PL(y, z), {
+      AffineActFwdOp<T, V, true> op; op.y = (const T*)y; op.z = (T*)z; op.a = a; op.b = b; op.pool = pool_part; op.act = act;
+      return launch_rows(op, n, rows, c, st, "affine_act_fwd");
+    });
+  } else {
+    DISPATCH_ROWS(dtype, c, PL(y, z), {
+      AffineActFwdOp<T, V, false> op; op.y = (const T*)y; op.z = (T*)z; op.a = a; op.b = b; op.pool = nullptr; op.act = act;
+      return launch_rows(op, n, rows, c, st, "affine_act_fwd");
+    });
+  }
+  return 0;
+}
+
+extern "C" int unet_affine_act_bwd_reduce(int32_t dtype, const void* y, const void* dz, const float* dpool,
+                                          const float* a, const float* b, int32_t act, float* g1_part,
+                                          float* g2_part, int32_t n, int32_t rows, int32_t c, void* stream) {
+  if (check_dims(n, rows, c, "affine_act_bwd_reduce")) return -1;
+  UNET_REQUIRE(y && dz && a && b && g1_part && g2_part, "affine_act_bwd_reduce: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH_ROWS(dtype, c, PL(y, dz), {
+    AffineActBwdOp<T, V, false> op; op.y = (const T*)y; op.dz = (const T*)dz; op.dpool = dpool; op.a = a; op.b = b;
+    op.act = act; op.g1 = g1_part; op.g2 = g2_part; op.ca = op.cb = op.cc = nullptr; op.dy = nullptr;
+    return launch_rows(op, n, rows, c, st, "affine_act_bwd_reduce");
+  });
+  return 0;
+}
+
+extern "C" int unet_affine_act_bwd_apply(int32_t dtype, const void* y, const void* dz, const float* dpool,
+                                         const float* a, const float* b, int32_t act, const float* ca,
+                                         const float* cb, const float* cc, void* dy, int32_t n, int32_t rows,
+                                         int32_t c, void* stream) {
+  if (check_dims(n, rows, c, "affine_act_bwd_apply")) return -1;
+  UNET_REQUIRE(y && dz && a && b && ca && cb && cc && dy, "affine_act_bwd_apply: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH_ROWS(dtype, c, PL(y, dz, dy), {
+    AffineActBwdOp<T, V, true> op; op.y = (const T*)y; op.dz = (const T*)dz; op.dpool = dpool; op.a = a; op.b = b;
+    op.act = act; op.g1 = op.g2 = nullptr; op.ca = ca; op.cb = cb; op.cc = cc; op.dy = (T*)dy;
+    return launch_rows(op, n, rows, c, st, "affine_act_bwd_apply");
+  });
+  return 0;
+}
+
+extern "C" int unet_scale_fwd(int32_t dtype, const void* x, const float* s, void* out, int32_t n, int32_t rows,
+                              int32_t c, void* stream) {
+  if (check_dims(n, rows, c, "scale_fwd")) return -1;
+  UNET_REQUIRE(x && s && out, "scale_fwd: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH_ROWS(dtype, c, PL(x, out), {
+    ScaleFwdOp<T, V> op; op.x = (const T*)x; op.out = (T*)out; op.s = s;
+    return launch_rows(op, n, rows, c, st, "scale_fwd");
+  });
+  return 0;
+}
+
+extern "C" int unet_scale_bwd(int32_t dtype, const void* x, const void* dout, const float* s, void* dx,
+                              float* ds_part, int32_t n, int32_t rows, int32_t c, void* stream) {
+  if (check_dims(n, rows, c, "scale_bwd")) return -1;
+  UNET_REQUIRE(x && dout && s && dx && ds_part, "scale_bwd: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH_ROWS(dtype, c, PL(x, dout, dx), {
+    ScaleBwdOp<T, V> op; op.x = (const T*)x; op.dout = (const T*)dout; op.dx = (T*)dx; op.s = s; op.ds = ds_part;
+    return launch_rows(op, n, rows, c, st, "scale_bwd");
+  });
+  return 0;
+}
+
+extern "C" int unet_gated_add_fwd(int32_t dtype, const void* res, const void* o, const float* g, void* out,
+                                  int32_t n, int32_t rows, int32_t c, void* stream) {
+  if (check_dims(n, rows, c, "gated_add_fwd")) return -1;
+  UNET_REQUIRE(res && o && g && out, "gated_add_fwd: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH_ROWS(dtype, c, PL(res, o, out), {
+    GatedAddFwdOp<T, V> op; op.res = (const T*)res; op.o = (const T*)o; op.out = (T*)out; op.g = g;
+    return launch_rows(op, n, rows, c, st, "gated_add_fwd");
+  });
+  return 0;
+}
+
+extern "C" int unet_gated_add_bwd(int32_t dtype, const void* o, const void* dout, const float* g, void* d_o,
+                                  float* dg_part, int32_t n, int32_t rows, int32_t c, void* stream) {
+  if (check_dims(n, rows, c, "gated_add_bwd")) return -1;
+  UNET_REQUIRE(o && dout && g && d_o && dg_part, "gated_add_bwd: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH_ROWS(dtype, c, PL(o, dout, d_o), {
+    GatedAddBwdOp<T, V> op; op.o = (const T*)o; op.dout = (const T*)dout; op.d_o = (T*)d_o; op.g = g; op.dg = dg_part;
+    return launch_rows(op, n, rows, c, st, "gated_add_bwd");
+  });
+  return 0;
+}
+
+extern "C" int unet_film_softmax_fwd(int32_t dtype, const void* q, const float* kk, const float* v, void* h,
+                                     int32_t n, int32_t rows, int32_t c, void* stream) {
+  return film_entry(false, dtype, q, nullptr, kk, v, h, nullptr, nullptr, n, rows, c, stream);
+}
+extern "C" int unet_film_softmax_bwd(int32_t dtype, const void* q, const void* dh, const float* kk,
+                                     const float* v, void* dq, float* dkk_part, float* dv_part, int32_t n,
+                                     int32_t rows, int32_t c, void* stream) {
+  return film_entry(true, dtype, q, dh, kk, v, dq, dkk_part, dv_part, n, rows, c, stream);
+}
+
+extern "C" int unet_ncl_moments(int32_t in_dtype, const void* x, float* mean, float* rstd, int32_t n, int32_t c,
+                                int32_t t, float eps, void* stream) {
+  UNET_REQUIRE(x && mean && rstd && n > 0 && c > 0 && t > 0, "ncl_moments: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long rows = (long long)n * c;
+  UNET_REQUIRE(rows < (1ll << 31), "ncl_moments: too many rows");
+  if (in_dtype == UNET_F32) hipLaunchKernelGGL(ncl_rowmoments_kernel<float>, dim3((unsigned)rows), dim3(THREADS), 0, st, (const float*)x, mean, rstd, t, eps);
+  else if (in_dtype == UNET_BF16) hipLaunchKernelGGL(ncl_rowmoments_kernel<__bf16>, dim3((unsigned)rows), dim3(THREADS), 0, st, (const __bf16*)x, mean, rstd, t, eps);
+  else { unet_set_error("ncl_moments: bad dtype %d", in_dtype); return -1; }
+  UNET_LAUNCH_CHECK("ncl_moments");
+  return 0;
+}
+
+extern "C" int unet_ncl_to_nlc(int32_t in_dtype, int32_t dtype, const void* x, const float* sub, const float* mul,
+                               void* y, int32_t n, int32_t c, int32_t t, void* stream) {
+  UNET_REQUIRE(x && y && n > 0 && c > 0 && t > 0 && n <= 65535, "ncl_to_nlc: bad arguments");
+  UNET_REQUIRE((sub == nullptr) == (mul == nullptr), "ncl_to_nlc: sub and mul must both be given or both be null");
+  UNET_REQUIRE(dtype == UNET_F32 || dtype == UNET_BF16, "ncl_to_nlc: bad dtype %d", dtype);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (in_dtype == UNET_F32) return transpose_in<float>(dtype, x, y, sub, mul, n, c, t, st);
+  if (in_dtype == UNET_BF16) return transpose_in<__bf16>(dtype, x, y, sub, mul, n, c, t, st);
+  unet_set_error("ncl_to_nlc: bad in_dtype %d", in_dtype);
+  return -1;
+}
+
+extern "C" int unet_nlc_to_ncl(int32_t dtype, int32_t out_dtype, const void* x, const void* x2, const float* ga,
+                               const float* gb, const float* be, void* y, int32_t n, int32_t c, int32_t t,
+                               void* stream) {
+  UNET_REQUIRE(x && y && n > 0 && c > 0 && t > 0 && n <= 65535, "nlc_to_ncl: bad arguments");
+  UNET_REQUIRE((x2 == nullptr) == (gb == nullptr), "nlc_to_ncl: x2 and gb must both be given or both be null");
+  UNET_REQUIRE(out_dtype == UNET_F32 || out_dtype == UNET_BF16, "nlc_to_ncl: bad out_dtype %d", out_dtype);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == UNET_F32) return transpose_out<float>(out_dtype, x, x2, y, ga, gb, be, n, c, t, st);
+  if (dtype == UNET_BF16) return transpose_out<__bf16>(out_dtype, x, x2, y, ga, gb, be, n, c, t, st);
+  unet_set_error("nlc_to_ncl: bad dtype %d", dtype);
+  return -1;
+}

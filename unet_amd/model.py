@@ -1,0 +1,735 @@
+"""CondUNet1D on hand-written CDNA4 kernels -- drop-in for the reference's model class.
+
+Same constructor keywords, ``forward`` signature, attribute names and ``state_dict()``
+key/shape layout as ``/root/reference/models.py:2865-3375`` (so checkpoints written by the
+reference's ``train.py:653-657`` load with ``strict=True`` and vice versa), and the same
+parameter creation order, so ``torch.manual_seed(s)`` before the constructor gives the same
+initial weights.
+
+What differs is everything underneath: parameters live in ordinary ``nn`` containers
+(``nn.Conv1d`` etc. are used as *parameter holders only* and are never called); the forward
+pass runs on channels-last bf16/fp32 activations through ``unet_amd.ops`` (HIP kernels via
+the C ABI).  Blocks hand each other ``[N, C, L]``-shaped views of channels-last storage, so
+forward hooks / ``extract_all_activations`` keep seeing the reference's tensor shapes.
+
+Hot-path scope: conv_type standard|modern, skip add|concat, every
+norm_type, cond none|cross_attn_gated, attention none|basic, scalar adaptive scaling.
+Out-of-scope constructor options raise ``NotImplementedError`` (never a silent fallback).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import ACT_IDS
+
+Tensor = torch.Tensor
+
+BASE_CHANNELS = 128  # models.py BASE_CHANNELS
+NUM_ODORS = 7        # models.py NUM_ODORS
+
+
+def get_activation_id(name: str) -> int:
+    """models.py:50-68 -- same names, same error."""
+    if name not in ("relu", "leaky_relu", "gelu", "silu", "mish"):
+        raise ValueError(f"Unknown activation: {name}. Available: ['relu', 'leaky_relu', 'gelu', 'silu', 'mish']")
+    return ACT_IDS[name]
+
+
+def _to_nlc(x: Tensor) -> Tensor:
+    """[N, C, L]-shaped tensor -> contiguous channels-last [N, L, C] (free when x is already a
+    view of channels-last storage)."""
+    y = x.permute(0, 2, 1)
+    if y.is_contiguous():
+        return y
+    if x.is_contiguous() and x.is_cuda:
+        return ops.ToNLCFn.apply(x, x.dtype)
+    return y.contiguous()
+
+
+def _as_ncl(x: Tensor) -> Tensor:
+    return x.permute(0, 2, 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# normalisation (models.py:537-555, 801-817) + activation (+ SE squeeze) on the HIP kernels
+# ---------------------------------------------------------------------------------------------
+def _make_norm(norm_type: str, c: int) -> nn.Module:
+    if norm_type == "instance":
+        return nn.InstanceNorm1d(c, affine=True)
+    if norm_type == "batch":
+        return nn.BatchNorm1d(c)
+    if norm_type == "group":
+        g = min(8, c)
+        while c % g != 0:
+            g -= 1
+        return nn.GroupNorm(g, c)
+    if norm_type in ("layer", "rms"):
+        return nn.GroupNorm(1, c)
+    if norm_type == "none":
+        return nn.Identity()
+    raise ValueError(f"Unknown norm_type: {norm_type}. Available: batch, instance, group, layer, rms, none")
+
+
+def _norm_act(y: Tensor, norm: nn.Module, act_id: int, want_pool: bool):
+    """z = act(norm(y)) (+ per-(window, channel) sum of z over rows) for y in NLC."""
+    n, rows, c = y.shape
+    if isinstance(norm, nn.Identity):
+        return ops.AffineActFn.apply(y, None, None, None, act_id, want_pool)
+    y = y.contiguous()
+    if isinstance(norm, nn.BatchNorm1d):
+        use_batch = norm.training or norm.running_mean is None
+        if use_batch:
+            s1, s2 = ops.rowstats(y)
+            cnt = n * rows
+            mean_c = s1.sum(0) / cnt
+            var_c = (s2.sum(0) / cnt - mean_c * mean_c).clamp_min(0.0)
+            if norm.training and norm.track_running_stats and norm.running_mean is not None:
+                with torch.no_grad():
+                    norm.num_batches_tracked += 1
+                    mom = norm.momentum
+                    if mom is None:
+                        mom = 1.0 / float(norm.num_batches_tracked)
+                    unbiased = var_c * (cnt / max(cnt - 1, 1))
+                    norm.running_mean.mul_(1 - mom).add_(mean_c.to(norm.running_mean.dtype), alpha=mom)
+                    norm.running_var.mul_(1 - mom).add_(unbiased.to(norm.running_var.dtype), alpha=mom)
+            rstd_c = torch.rsqrt(var_c + norm.eps)
+            stats = dict(mean=mean_c[None, :].expand(n, c), rstd=rstd_c[None, :].expand(n, c), coupled=True,
+                         count=float(cnt), reduce=lambda v: v.sum(0, keepdim=True))
+        else:
+            mean_c = norm.running_mean.double()
+            rstd_c = torch.rsqrt(norm.running_var.double() + norm.eps)
+            stats = dict(mean=mean_c[None, :].expand(n, c), rstd=rstd_c[None, :].expand(n, c), coupled=False)
+        return ops.AffineActFn.apply(y, norm.weight, norm.bias, stats, act_id, want_pool)
+    if isinstance(norm, nn.InstanceNorm1d):
+        s1, s2 = ops.rowstats(y)
+        mean = s1 / rows
+        var = (s2 / rows - mean * mean).clamp_min(0.0)
+        stats = dict(mean=mean, rstd=torch.rsqrt(var + norm.eps), coupled=True, count=float(rows),
+                     reduce=lambda v: v)
+        return ops.AffineActFn.apply(y, norm.weight, norm.bias, stats, act_id, want_pool)
+    if isinstance(norm, nn.GroupNorm):
+        g = norm.num_groups
+        s1, s2 = ops.rowstats(y)
+        cnt = rows * (c // g)
+
+        def red(v, g=g, n=n, c=c):
+            return v.reshape(n, g, c // g).sum(-1, keepdim=True).expand(n, g, c // g).reshape(n, c)
+
+        mean = red(s1) / cnt
+        var = (red(s2) / cnt - mean * mean).clamp_min(0.0)
+        stats = dict(mean=mean, rstd=torch.rsqrt(var + norm.eps), coupled=True, count=float(cnt), reduce=red)
+        return ops.AffineActFn.apply(y, norm.weight, norm.bias, stats, act_id, want_pool)
+    raise TypeError(f"unsupported norm module {type(norm)}")
+
+
+# ---------------------------------------------------------------------------------------------
+# blocks (parameter layout = the reference's; compute = HIP ops)
+# ---------------------------------------------------------------------------------------------
+class SelfAttention1D(nn.Module):
+    """models.py:75-97.  1x1 projections on the HIP conv kernel; the two batched products and
+    the softmax of this constructor-default-only bottleneck layer use torch (rocBLAS)."""
+
+    def __init__(self, channels: int, reduction: int = 8):
+        super().__init__()
+        self.channels = channels
+        self.query = nn.Conv1d(channels, channels // reduction, kernel_size=1)
+        self.key = nn.Conv1d(channels, channels // reduction, kernel_size=1)
+        self.value = nn.Conv1d(channels, channels, kernel_size=1)
+        self.gamma = nn.Parameter(torch.zeros(1))
+
+    def forward_nlc(self, x: Tensor) -> Tensor:
+        g1 = ops.geom_conv(1)
+        l = x.shape[1]
+        q = ops.conv(x, self.query.weight.permute(2, 0, 1), self.query.bias, g1, l)
+        k = ops.conv(x, self.key.weight.permute(2, 0, 1), self.key.bias, g1, l)
+        v = ops.conv(x, self.value.weight.permute(2, 0, 1), self.value.bias, g1, l)
+        att = torch.softmax(torch.bmm(q, k.transpose(1, 2)).float(), dim=-1).to(x.dtype)
+        out = torch.bmm(att, v)
+        return (x.float() + self.gamma.float() * out.float()).to(x.dtype)  # fp32 so d(gamma) reduces in fp32
+
+    def forward(self, x: Tensor) -> Tensor:
+        return _as_ncl(self.forward_nlc(_to_nlc(x)))
+
+
+class FiLM(nn.Module):
+    """models.py:477-517 (cross-attention with output gating; 'none' bypasses)."""
+
+    def __init__(self, channels: int, emb_dim: int, cond_mode: str = "cross_attn_gated"):
+        super().__init__()
+        self.cond_mode = cond_mode
+        self.channels = channels
+        self.emb_dim = emb_dim
+        if cond_mode == "cross_attn_gated":
+            self.q_proj = nn.Conv1d(channels, channels, 1)
+            self.k_proj = nn.Linear(emb_dim, channels)
+            self.v_proj = nn.Linear(emb_dim, channels)
+            self.out_proj = nn.Conv1d(channels, channels, 1)
+            self.scale_factor = channels ** -0.5
+            self.gate = nn.Sequential(nn.Linear(emb_dim, channels), nn.Sigmoid())
+        elif cond_mode != "none":
+            raise ValueError(f"Unknown cond_mode: {cond_mode}. Supported: 'none', 'cross_attn_gated'")
+
+    def forward_nlc(self, x: Tensor, emb: Optional[Tensor]) -> Tensor:
+        if self.cond_mode == "none" or emb is None:
+            return x
+        emb = emb.float()
+        g1 = ops.geom_conv(1)
+        l = x.shape[1]
+        q = ops.conv(x, self.q_proj.weight.permute(2, 0, 1), self.q_proj.bias, g1, l)
+        kk = self.k_proj(emb) * self.scale_factor
+        v = self.v_proj(emb)
+        h = ops.FilmSoftmaxFn.apply(q, kk, v)
+        o = ops.conv(h, self.out_proj.weight.permute(2, 0, 1), self.out_proj.bias, g1, l)
+        return ops.GatedAddFn.apply(x, o, self.gate(emb))
+
+    def forward(self, x: Tensor, emb: Optional[Tensor] = None) -> Tensor:
+        if self.cond_mode == "none" or emb is None:
+            return x
+        return _as_ncl(self.forward_nlc(_to_nlc(x), emb))
+
+
+class ConvBlock(nn.Module):
+    """models.py:520-569: film(Sequential[Conv1d k3, norm, GELU, (Dropout1d)](x), emb)."""
+
+    def __init__(self, in_c: int, out_c: int, emb_dim: int, downsample: bool = False, dropout: float = 0.0,
+                 norm_type: str = "batch", cond_mode: str = "cross_attn_gated"):
+        super().__init__()
+        self.stride = 2 if downsample else 1
+        self.cond_mode = cond_mode
+        norm = _make_norm(norm_type, out_c)
+        layers: List[nn.Module] = [nn.Conv1d(in_c, out_c, kernel_size=3, stride=self.stride, padding=1), norm, nn.GELU()]
+        if dropout > 0:
+            layers.append(nn.Dropout1d(p=dropout))
+        self.dropout_p = dropout
+        self.conv = nn.Sequential(*layers)
+        self.film = FiLM(out_c, emb_dim, cond_mode=cond_mode)
+
+    def _main_conv(self, x1: Tensor, x2: Optional[Tensor]) -> Tensor:
+        c = self.conv[0]
+        l_out = ops.conv_out_len(x1.shape[1], 3, self.stride)
+        return ops.conv(x1, c.weight.permute(2, 0, 1), c.bias, ops.geom_conv(3, self.stride), l_out, x2=x2)
+
+    def forward_nlc(self, x1: Tensor, emb: Optional[Tensor], x2: Optional[Tensor] = None) -> Tensor:
+        y = self._main_conv(x1, x2)
+        z = _norm_act(y, self.conv[1], ACT_IDS["gelu"], False)
+        z = _dropout1d_nlc(z, self.dropout_p, self.training)
+        return self.film.forward_nlc(z, emb)
+
+    def forward(self, x: Tensor, emb: Optional[Tensor] = None) -> Tensor:
+        return _as_ncl(self.forward_nlc(_to_nlc(x), emb))
+
+
+def _dropout1d_nlc(z: Tensor, p: float, training: bool) -> Tensor:
+    """nn.Dropout1d zeroes whole (window, channel) rows; on NLC that is a [N, 1, C] mask.
+    p = 0 in every production config; the mask uses torch's generator."""
+    if p <= 0 or not training:
+        return z
+    n, _, c = z.shape
+    keep = (torch.rand((n, c), device=z.device) >= p).to(torch.float32) / (1.0 - p)
+    return ops.ScaleFn.apply(z, keep)
+
+
+class SqueezeExcitation1D(nn.Module):
+    """models.py:637-662.  The squeeze (mean over L) arrives as a by-product of the fused
+    norm+GELU pass; only the [N, C] MLP runs here."""
+
+    def __init__(self, channels: int, reduction: int = 4):
+        super().__init__()
+        self.pool = nn.AdaptiveAvgPool1d(1)
+        reduced = max(channels // reduction, 8)
+        self.fc = nn.Sequential(nn.Linear(channels, reduced, bias=False), nn.GELU(),
+                                nn.Linear(reduced, channels, bias=False), nn.Sigmoid())
+
+    def gate_from_pool(self, pool_sum: Tensor, rows: int) -> Tensor:
+        return self.fc(pool_sum / rows)
+
+    def forward(self, x: Tensor) -> Tensor:
+        xn = _to_nlc(x)
+        z, pool = ops.AffineActFn.apply(xn, None, None, None, 0, True)
+        return _as_ncl(ops.ScaleFn.apply(z, self.gate_from_pool(pool, xn.shape[1])))
+
+
+class DilatedConv1d(nn.Module):
+    """models.py:665-702 (parameter holder for one branch)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 7, stride: int = 1, dilation: int = 1):
+        super().__init__()
+        padding = (kernel_size - 1) * dilation // 2
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                              dilation=dilation, bias=True)
+
+
+class MultiScaleDilatedConv1d(nn.Module):
+    """models.py:705-759.  The weighted sum of the parallel dilated branches is evaluated as ONE
+    tap-list convolution: W_eff[tap] = sum over (branch, k) landing on that tap of
+    softmax(scale_weights)[branch] * W_branch[:, :, k]; gradients reach every branch weight,
+    bias and scale_weights through autograd on this (tiny) weight algebra."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 7, stride: int = 1,
+                 dilations: Tuple[int, ...] = (1, 4, 16, 32)):
+        super().__init__()
+        self.n_scales = len(dilations)
+        self.kernel_size, self.stride, self.dilations = kernel_size, stride, tuple(dilations)
+        self.branches = nn.ModuleList([
+            DilatedConv1d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, dilation=d)
+            for d in dilations])
+        self.scale_weights = nn.Parameter(torch.ones(self.n_scales) / self.n_scales)
+        g, pairs = ops.merged_dilated_taps(kernel_size, self.dilations)
+        self._geom = ops.ConvGeom(g.offs, g.phases, stride, 1)
+        self.register_buffer("_tap_index", torch.tensor([p[2] for p in pairs], dtype=torch.long), persistent=False)
+
+    def effective_weights(self) -> Tuple[Tensor, Tensor]:
+        w = F.softmax(self.scale_weights.float(), dim=0)
+        ws = torch.stack([b.conv.weight for b in self.branches], dim=0).float()      # [B, Co, Ci, K]
+        ws = (ws * w[:, None, None, None]).permute(0, 3, 1, 2)                         # [B, K, Co, Ci]
+        ws = ws.reshape(-1, ws.shape[2], ws.shape[3])                                  # [(b,k), Co, Ci]
+        w_eff = torch.zeros((self._geom.n_taps,) + tuple(ws.shape[1:]), dtype=ws.dtype, device=ws.device)
+        w_eff = w_eff.index_add(0, self._tap_index, ws)
+        b_eff = (torch.stack([b.conv.bias for b in self.branches], dim=0).float() * w[:, None]).sum(0)
+        return w_eff, b_eff
+
+    def forward_nlc(self, x1: Tensor, x2: Optional[Tensor] = None) -> Tensor:
+        w_eff, b_eff = self.effective_weights()
+        k, s = self.kernel_size, self.stride
+        l_out = ops.conv_out_len(x1.shape[1], k, s, 1)
+        return ops.conv(x1, w_eff, b_eff, self._geom, l_out, x2=x2)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return _as_ncl(self.forward_nlc(_to_nlc(x)))
+
+
+class ModernConvBlock(nn.Module):
+    """models.py:762-840: film(Sequential[multi-dilated conv, norm, GELU, (SE), (Dropout1d)](x), emb)."""
+
+    def __init__(self, in_c: int, out_c: int, emb_dim: int, downsample: bool = False, dropout: float = 0.0,
+                 norm_type: str = "batch", cond_mode: str = "cross_attn_gated", use_se: bool = True,
+                 kernel_size: int = 7, dilations: Tuple[int, ...] = (1, 4, 16, 32)):
+        super().__init__()
+        stride = 2 if downsample else 1
+        self.use_se = use_se
+        norm = _make_norm(norm_type, out_c)
+        conv = MultiScaleDilatedConv1d(in_c, out_c, kernel_size=kernel_size, stride=stride, dilations=dilations)
+        layers: List[nn.Module] = [conv, norm, nn.GELU()]
+        if self.use_se:
+            layers.append(SqueezeExcitation1D(out_c))
+        if dropout > 0:
+            layers.append(nn.Dropout1d(p=dropout))
+        self.dropout_p = dropout
+        self.conv = nn.Sequential(*layers)
+        self.film = FiLM(out_c, emb_dim, cond_mode=cond_mode)
+
+    def forward_nlc(self, x1: Tensor, emb: Optional[Tensor], x2: Optional[Tensor] = None) -> Tensor:
+        y = self.conv[0].forward_nlc(x1, x2)
+        if self.use_se:
+            z, pool = _norm_act(y, self.conv[1], ACT_IDS["gelu"], True)
+            z = ops.ScaleFn.apply(z, self.conv[3].gate_from_pool(pool, z.shape[1]))
+        else:
+            z = _norm_act(y, self.conv[1], ACT_IDS["gelu"], False)
+        z = _dropout1d_nlc(z, self.dropout_p, self.training)
+        return self.film.forward_nlc(z, emb)
+
+    def forward(self, x: Tensor, emb: Optional[Tensor] = None) -> Tensor:
+        return _as_ncl(self.forward_nlc(_to_nlc(x), emb))
+
+
+class _UpMixin:
+    """models.py:611-630 / 916-936: ConvTranspose1d(k4,s2,p1) -> centre-crop -> concat | add -> block.
+    The transposed conv runs as a two-phase tap-list conv; `add` is fused into its epilogue and
+    `concat` is never materialised (the block's first conv reads two sources)."""
+
+    def _up_forward(self, x: Tensor, skip: Tensor, emb: Optional[Tensor]) -> Tensor:
+        geom, kidx = ops.geom_convt_k4s2p1()
+        w = self.up.weight.permute(2, 1, 0)[list(kidx)]          # [4 taps, Cout, Cin]
+        l_up = 2 * x.shape[1]
+        l_skip = skip.shape[1]
+        if self.skip_type == "add" and self.skip_proj is not None:
+            skip = ops.conv(skip, self.skip_proj.weight.permute(2, 0, 1), self.skip_proj.bias, ops.geom_conv(1), l_skip)
+        if self.skip_type == "add" and l_up == l_skip:
+            u = ops.conv(x, w, self.up.bias, geom, l_up, res=skip)
+            return self.block.forward_nlc(u, emb)
+        u = ops.conv(x, w, self.up.bias, geom, l_up)
+        if l_up < l_skip:
+            s = (l_skip - l_up) // 2
+            skip = skip[:, s:s + l_up, :]
+        elif l_up > l_skip:
+            s = (l_up - l_skip) // 2
+            u = u[:, s:s + l_skip, :]
+        if self.skip_type == "concat":
+            return self.block.forward_nlc(u, emb, x2=skip)
+        return self.block.forward_nlc(u + skip, emb)
+
+
+class UpBlock(nn.Module, _UpMixin):
+    def __init__(self, in_c: int, skip_c: int, out_c: int, emb_dim: int, dropout: float = 0.0,
+                 norm_type: str = "batch", cond_mode: str = "cross_attn_gated", skip_type: str = "concat"):
+        super().__init__()
+        self.skip_type = skip_type
+        self.up = nn.ConvTranspose1d(in_c, out_c, kernel_size=4, stride=2, padding=1)
+        if skip_type == "concat":
+            self.block = ConvBlock(out_c + skip_c, out_c, emb_dim, downsample=False, dropout=dropout,
+                                   norm_type=norm_type, cond_mode=cond_mode)
+            self.skip_proj = None
+        elif skip_type == "add":
+            self.block = ConvBlock(out_c, out_c, emb_dim, downsample=False, dropout=dropout, norm_type=norm_type,
+                                   cond_mode=cond_mode)
+            self.skip_proj = nn.Conv1d(skip_c, out_c, kernel_size=1) if skip_c != out_c else None
+        else:
+            raise ValueError(f"Unknown skip_type: {skip_type}. Available: concat, add")
+
+    def forward_nlc(self, x, skip, emb):
+        return self._up_forward(x, skip, emb)
+
+    def forward(self, x: Tensor, skip: Tensor, emb: Optional[Tensor] = None) -> Tensor:
+        return _as_ncl(self._up_forward(_to_nlc(x), _to_nlc(skip), emb))
+
+
+class ModernUpBlock(nn.Module, _UpMixin):
+    def __init__(self, in_c: int, skip_c: int, out_c: int, emb_dim: int, dropout: float = 0.0,
+                 norm_type: str = "batch", cond_mode: str = "cross_attn_gated", use_se: bool = True,
+                 kernel_size: int = 7, dilations: Tuple[int, ...] = (1, 4, 16, 32), skip_type: str = "concat"):
+        super().__init__()
+        self.skip_type = skip_type
+        self.up = nn.ConvTranspose1d(in_c, out_c, kernel_size=4, stride=2, padding=1)
+        kw = dict(downsample=False, dropout=dropout, norm_type=norm_type, cond_mode=cond_mode, use_se=use_se,
+                  kernel_size=kernel_size, dilations=dilations)
+        if skip_type == "concat":
+            self.block = ModernConvBlock(out_c + skip_c, out_c, emb_dim, **kw)
+            self.skip_proj = None
+        elif skip_type == "add":
+            self.block = ModernConvBlock(out_c, out_c, emb_dim, **kw)
+            self.skip_proj = nn.Conv1d(skip_c, out_c, kernel_size=1) if skip_c != out_c else None
+        else:
+            raise ValueError(f"Unknown skip_type: {skip_type}. Available: concat, add")
+
+    def forward_nlc(self, x, skip, emb):
+        return self._up_forward(x, skip, emb)
+
+    def forward(self, x: Tensor, skip: Tensor, emb: Optional[Tensor] = None) -> Tensor:
+        return _as_ncl(self._up_forward(_to_nlc(x), _to_nlc(skip), emb))
+
+
+class _Act(nn.Module):
+    """Parameter-free stand-in for the activation modules of ``self.mid`` (keeps the
+    reference's Sequential indices: mid.0 conv, mid.1 act, [mid.2 attention], conv, act)."""
+
+    def __init__(self, name: str):
+        super().__init__()
+        self.name = name
+        self.act_id = get_activation_id(name)
+
+    def forward_nlc(self, x: Tensor) -> Tensor:
+        return ops.activation(x, self.act_id)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return _as_ncl(self.forward_nlc(_to_nlc(x)))
+
+    def extra_repr(self) -> str:
+        return self.name
+
+
+class _Bottleneck(nn.Sequential):
+    """``self.mid`` (models.py:3029-3041) -- an nn.Sequential so indices/keys match; forward is
+    overridden to stay channels-last between its layers."""
+
+    def forward_nlc(self, x: Tensor) -> Tensor:
+        for m in self:
+            if isinstance(m, nn.Conv1d):
+                x = ops.conv(x, m.weight.permute(2, 0, 1), m.bias, ops.geom_conv(3), x.shape[1])
+            else:
+                x = m.forward_nlc(x)
+        return x
+
+    def forward(self, x: Tensor) -> Tensor:
+        return _as_ncl(self.forward_nlc(_to_nlc(x)))
+
+
+class SessionAdaptiveScaling(nn.Module):
+    """models.py:1998-2068 (scalar mode).  Statistics come from the HIP moments kernel; the
+    64-wide predictor MLP and the final [N, C_out, T] affine are tiny and stay in torch."""
+
+    def __init__(self, n_channels: int, n_input_channels: int = 32, hidden_dim: int = 64):
+        super().__init__()
+        self.n_channels = n_channels
+        self.n_input_channels = n_input_channels
+        input_dim = n_input_channels * 2
+        self.predictor = nn.Sequential(
+            nn.Linear(input_dim, hidden_dim), nn.LayerNorm(hidden_dim), nn.GELU(),
+            nn.Linear(hidden_dim, hidden_dim), nn.LayerNorm(hidden_dim), nn.GELU(),
+            nn.Linear(hidden_dim, n_channels * 2))
+        nn.init.zeros_(self.predictor[-1].weight)
+        with torch.no_grad():
+            self.predictor[-1].bias[:n_channels] = 1.0
+            self.predictor[-1].bias[n_channels:] = 0.0
+
+    def forward(self, x: Tensor, raw_input: Tensor) -> Tensor:
+        mean = raw_input.float().mean(dim=-1)
+        std = raw_input.float().std(dim=-1)
+        params = self.predictor(torch.cat([mean, std], dim=-1))
+        gamma = params[:, :self.n_channels].unsqueeze(-1).to(x.dtype)
+        beta = params[:, self.n_channels:].unsqueeze(-1).to(x.dtype)
+        return x * gamma + beta
+
+
+class CondUNet1D(nn.Module):
+    """Drop-in for models.py:2865-3375 on the MI355X kernels (see module docstring)."""
+
+    def __init__(
+        self,
+        in_channels: int = 32,
+        out_channels: int = 32,
+        base: int = BASE_CHANNELS,
+        n_odors: int = NUM_ODORS,
+        emb_dim: int = 128,
+        dropout: float = 0.0,
+        use_attention: bool = True,
+        attention_type: str = "basic",
+        norm_type: str = "batch",
+        cond_mode: str = "cross_attn_gated",
+        n_downsample: int = 2,
+        conv_type: str = "standard",
+        use_se: bool = True,
+        conv_kernel_size: int = 7,
+        dilations: Tuple[int, ...] = (1, 4, 16, 32),
+        use_adaptive_scaling: bool = False,
+        adaptive_scaling_mode: str = "scalar",
+        adaptive_scaling_cross_channel: bool = False,
+        use_session_stats: bool = False,
+        session_emb_dim: int = 32,
+        session_use_spectral: bool = False,
+        use_session_embedding: bool = False,
+        n_sessions: int = 0,
+        activation: str = "relu",
+        n_heads: int = 4,
+        skip_type: str = "add",
+        sampling_rate: float = 1000.0,
+    ):
+        super().__init__()
+        self.cond_mode = cond_mode
+        self.emb_dim = emb_dim
+        self.attention_type = attention_type
+        self.conv_type = conv_type
+        self.n_downsample = n_downsample
+        self.use_session_stats = use_session_stats
+        self.use_session_embedding = use_session_embedding
+        self.session_emb_dim = session_emb_dim
+        self.n_sessions = n_sessions
+        self.activation_name = activation
+        self.n_heads = n_heads
+        self.skip_type = skip_type
+
+        if use_session_stats or use_session_embedding:
+            raise NotImplementedError(
+                "session statistics / session embedding conditioning is outside the hot-path scope "
+                "(SURVEY.md 2.1: ablation-only); use the reference implementation for it")
+        if use_session_embedding and n_sessions <= 0:
+            raise ValueError(f"use_session_embedding=True requires n_sessions > 0, got {n_sessions}")
+
+        self.embed = nn.Embedding(n_odors, emb_dim) if cond_mode != "none" else None
+        self.session_stats_encoder = None
+        self.session_proj = None
+        self.session_embed = None
+        self.session_embed_proj = None
+
+        channels = [base]
+        for i in range(n_downsample):
+            channels.append(min(base * (2 ** (i + 1)), base * 8))
+
+        if conv_type == "modern":
+            kw = dict(use_se=use_se, kernel_size=conv_kernel_size, dilations=dilations)
+            self.inc = ModernConvBlock(in_channels, channels[0], emb_dim, dropout=dropout, norm_type=norm_type,
+                                       cond_mode=cond_mode, **kw)
+            self.encoders = nn.ModuleList([
+                ModernConvBlock(channels[i], channels[i + 1], emb_dim, downsample=True, dropout=dropout,
+                                norm_type=norm_type, cond_mode=cond_mode, **kw) for i in range(n_downsample)])
+            self.decoders = nn.ModuleList([
+                ModernUpBlock(channels[n_downsample - i], channels[n_downsample - i - 1], channels[n_downsample - i - 1],
+                              emb_dim, dropout=dropout, norm_type=norm_type, cond_mode=cond_mode, skip_type=skip_type,
+                              **kw) for i in range(n_downsample)])
+        else:
+            self.inc = ConvBlock(in_channels, channels[0], emb_dim, dropout=dropout, norm_type=norm_type,
+                                 cond_mode=cond_mode)
+            self.encoders = nn.ModuleList([
+                ConvBlock(channels[i], channels[i + 1], emb_dim, downsample=True, dropout=dropout, norm_type=norm_type,
+                          cond_mode=cond_mode) for i in range(n_downsample)])
+            self.decoders = nn.ModuleList([
+                UpBlock(channels[n_downsample - i], channels[n_downsample - i - 1], channels[n_downsample - i - 1],
+                        emb_dim, dropout=dropout, norm_type=norm_type, cond_mode=cond_mode, skip_type=skip_type)
+                for i in range(n_downsample)])
+
+        bottleneck_ch = channels[n_downsample]
+        mid_layers: List[nn.Module] = [nn.Conv1d(bottleneck_ch, bottleneck_ch, kernel_size=3, padding=1), _Act(activation)]
+        if use_attention and attention_type != "none":
+            mid_layers.append(self._build_attention(bottleneck_ch, attention_type))
+        mid_layers.extend([nn.Conv1d(bottleneck_ch, bottleneck_ch, kernel_size=3, padding=1), _Act(activation)])
+        self.mid = _Bottleneck(*mid_layers)
+
+        self.outc = nn.Conv1d(channels[0], out_channels, kernel_size=3, padding=1)
+        self.use_residual = (in_channels == out_channels)
+        if not self.use_residual:
+            self.residual_conv = nn.Conv1d(in_channels, out_channels, kernel_size=1)
+        nn.init.zeros_(self.outc.weight)
+        nn.init.zeros_(self.outc.bias)
+
+        self.use_adaptive_scaling = use_adaptive_scaling
+        self.adaptive_scaling_mode = adaptive_scaling_mode
+        if use_adaptive_scaling:
+            if adaptive_scaling_mode == "scalar" and not adaptive_scaling_cross_channel:
+                self.adaptive_scaler = SessionAdaptiveScaling(n_channels=out_channels, n_input_channels=in_channels)
+            else:
+                raise NotImplementedError("SessionAdaptiveScalingV3 (spectral/harmonic/cross-channel) is outside the "
+                                          "hot-path scope (SURVEY.md 2.1)")
+
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.base = base
+        self.use_attention = use_attention
+        self.gradient_checkpointing = False
+        self.compute_dtype: Optional[torch.dtype] = None  # None: follow the input's dtype
+
+    # -- reference API surface ---------------------------------------------------------------
+    def _build_attention(self, channels: int, attention_type: str) -> nn.Module:
+        if attention_type == "basic":
+            return SelfAttention1D(channels)
+        if attention_type in ("cross_freq", "cross_freq_v2"):
+            raise NotImplementedError(f"attention_type={attention_type!r} is a 'next' row (SURVEY.md 8f N3), not built yet")
+        raise ValueError(f"Unknown attention_type: {attention_type}. Available: none, basic, cross_freq, cross_freq_v2")
+
+    def set_gradient_checkpointing(self, enable: bool = True):
+        self.gradient_checkpointing = enable
+
+    def set_compute_dtype(self, dtype: Optional[torch.dtype]):
+        """bf16 or fp32 kernels regardless of the input dtype (None = follow the input)."""
+        if dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float32, torch.bfloat16 or None")
+        self.compute_dtype = dtype
+
+    def enable_adabn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                m.training = True
+                m.reset_running_stats()
+
+    def disable_adabn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                m.training = False
+
+    def calibrate_bn_stats(self, dataloader, device: torch.device, max_batches: int = 50):
+        self.train()
+        with torch.no_grad():
+            for i, batch in enumerate(dataloader):
+                if i >= max_batches:
+                    break
+                x = batch[0] if isinstance(batch, (list, tuple)) else batch
+                _ = self(x.to(device))
+        self.eval()
+
+    def get_layer_names(self) -> List[str]:
+        names = ["inc"] + [f"encoders.{i}" for i in range(self.n_downsample)] + ["mid"]
+        names += [f"decoders.{i}" for i in range(self.n_downsample)] + ["outc"]
+        return names
+
+    def get_gradient_norms(self) -> dict:
+        """Per-block norm of the first conv weight's gradient (models.py:3497)."""
+        out = {}
+        blocks = [("inc", self.inc)] + [(f"encoders.{i}", m) for i, m in enumerate(self.encoders)] + \
+                 [(f"decoders.{i}", m) for i, m in enumerate(self.decoders)]
+        for name, blk in blocks:
+            for p in blk.parameters():
+                if p.dim() == 3 and p.grad is not None:
+                    out[name] = float(p.grad.norm())
+                    break
+        return out
+
+    # -- forward --------------------------------------------------------------------------------
+    def forward(
+        self,
+        ob: Tensor,
+        odor_ids: Optional[Tensor] = None,
+        cond_emb: Optional[Tensor] = None,
+        session_ids: Optional[Tensor] = None,
+        return_bottleneck: bool = False,
+        return_bottleneck_temporal: bool = False,
+    ) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+        if ob.dim() != 3 or ob.shape[1] != self.in_channels:
+            raise ValueError(f"expected input [B, {self.in_channels}, T], got {tuple(ob.shape)}")
+        if not ob.is_cuda:
+            raise RuntimeError("unet_amd.CondUNet1D runs on the GPU only (HIP kernels); move the input to cuda")
+        raw_input = ob
+        io_dtype = ob.dtype if ob.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        if ob.dtype != io_dtype:
+            ob = ob.to(io_dtype)
+        cdt = self.compute_dtype or io_dtype
+
+        x0 = ops.ZScoreInFn.apply(ob, cdt)                       # models.py:3235, now channels-last
+
+        if cond_emb is not None:
+            emb = cond_emb
+        elif self.embed is not None and odor_ids is not None:
+            emb = self.embed(odor_ids)
+        else:
+            emb = None
+
+        def run(block, *a):
+            if self.gradient_checkpointing and self.training:
+                from torch.utils.checkpoint import checkpoint
+                return checkpoint(block.forward_nlc, *a, use_reentrant=False)
+            return block.forward_nlc(*a)
+
+        skips = [_HookedCall.run(self.inc, run, x0, emb)]
+        for enc in self.encoders:
+            skips.append(_HookedCall.run(enc, run, skips[-1], emb))
+
+        bottleneck = _HookedCall.run(self.mid, lambda blk, x: blk.forward_nlc(x), skips[-1])
+        if return_bottleneck_temporal:
+            bott = _as_ncl(bottleneck).to(io_dtype)
+        elif return_bottleneck:
+            bott = bottleneck.float().mean(dim=1).to(io_dtype)
+        else:
+            bott = None
+
+        x = bottleneck
+        for i, dec in enumerate(self.decoders):
+            x = _HookedCall.run(dec, run, x, skips[self.n_downsample - i - 1], emb)
+
+        l = x.shape[1]
+        if self.use_residual:
+            res = x0
+        else:
+            res = ops.conv(x0, self.residual_conv.weight.permute(2, 0, 1), self.residual_conv.bias, ops.geom_conv(1), l)
+        out_nlc = ops.conv(x, self.outc.weight.permute(2, 0, 1), self.outc.bias, ops.geom_conv(3), l, res=res)
+        out = ops.ToNCLFn.apply(out_nlc, io_dtype)
+        if self.use_adaptive_scaling:
+            out = self.adaptive_scaler(out, raw_input)
+        if return_bottleneck or return_bottleneck_temporal:
+            return out, bott
+        return out
+
+
+class _HookedCall:
+    """Runs a block's channels-last path while still honouring forward (pre-)hooks registered on
+    the block (register_activation_hooks / extract_all_activations in the reference): hooks see
+    and may replace ``[N, C, L]``-shaped views, exactly the tensors the reference's hooks get."""
+
+    @staticmethod
+    def run(block: nn.Module, runner, *args):
+        if not (block._forward_hooks or block._forward_pre_hooks):
+            return runner(block, *args)
+        ncl_args = tuple(_as_ncl(a) if (torch.is_tensor(a) and a.dim() == 3) else a for a in args)
+        for hook in block._forward_pre_hooks.values():
+            r = hook(block, ncl_args)
+            if r is not None:
+                ncl_args = r if isinstance(r, tuple) else (r,)
+        nlc_args = tuple(_to_nlc(a) if (torch.is_tensor(a) and a.dim() == 3) else a for a in ncl_args)
+        out = runner(block, *nlc_args)
+        out_ncl = _as_ncl(out)
+        for hook in block._forward_hooks.values():
+            r = hook(block, ncl_args, out_ncl)
+            if r is not None:
+                out_ncl = r
+        return _to_nlc(out_ncl)

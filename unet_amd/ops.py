@@ -1,0 +1,572 @@
+"""Autograd bindings of the HIP kernels (libunet_hip.so) for channels-last activations.
+
+Every heavy tensor op of the CondUNet1D hot path is a ``torch.autograd.Function`` whose
+forward and backward call the C ABI with raw device pointers on torch's current stream.
+PyTorch provides memory, streams and the autograd tape only; tiny per-(window, channel)
+algebra (norm statistics finalisation, SE/FiLM MLPs on [N, C] vectors) stays in torch.
+
+All activations here are "NLC": contiguous ``[N, L, C]`` (channels last), dtype bf16 or fp32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_IDS, ConvDesc, check
+
+Tensor = torch.Tensor
+
+
+# ---------------------------------------------------------------------------------------------
+# plumbing
+# ---------------------------------------------------------------------------------------------
+def _dt(t: Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return _lib.BF16
+    if t.dtype == torch.float32:
+        return _lib.F32
+    raise TypeError(f"unet_amd kernels take bfloat16 or float32 activations, got {t.dtype}")
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _need_cuda(t: Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("unet_amd kernels run on the GPU only (tensor is on %s); there is no CPU path" % t.device)
+
+
+def _nlc_ok(t: Tensor) -> Tensor:
+    """Rows may be a strided slice of a longer tensor; channels must be dense."""
+    if t.dim() != 3:
+        raise ValueError(f"expected [N, L, C], got {tuple(t.shape)}")
+    if t.stride(2) != 1 or t.stride(1) < t.shape[2]:
+        t = t.contiguous()
+    return t
+
+
+def _f32c(t: Tensor) -> Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def parts(rows: int) -> int:
+    return int(_lib.load().unet_parts(rows))
+
+
+# ---------------------------------------------------------------------------------------------
+# convolution geometry (tap lists)
+# ---------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class ConvGeom:
+    """y[up*m + phase_j] += W_j x[stride*m + off_j]; taps grouped by phase."""
+    offs: Tuple[int, ...]
+    phases: Tuple[int, ...]
+    stride: int = 1
+    up: int = 1
+
+    @property
+    def n_taps(self) -> int:
+        return len(self.offs)
+
+    def out_len(self, l_in: int, k_eff_pad: Optional[Tuple[int, int, int]] = None) -> int:
+        raise NotImplementedError
+
+    def dgrad(self) -> Tuple["ConvGeom", List[int]]:
+        """Geometry of the data gradient and, for each of ITS taps, the forward tap it uses."""
+        taps = []
+        for j, (o, r) in enumerate(zip(self.offs, self.phases)):
+            if self.up == 1 and self.stride == 1:
+                taps.append((0, -o, j))
+            elif self.up == 1 and self.stride == 2:
+                rp = o % 2             # dx row i = 2m + off_j, so this tap feeds rows of parity off_j mod 2
+                taps.append((rp, (rp - o) // 2, j))
+            elif self.up == 2 and self.stride == 1:
+                taps.append((0, r - 2 * o, j))
+            else:
+                raise ValueError("unsupported geometry")
+        taps.sort(key=lambda t: (t[0], t[1]))
+        if self.up == 1 and self.stride == 1:
+            g = ConvGeom(tuple(t[1] for t in taps), tuple(0 for _ in taps), 1, 1)
+        elif self.up == 1 and self.stride == 2:
+            g = ConvGeom(tuple(t[1] for t in taps), tuple(t[0] for t in taps), 1, 2)
+        else:
+            g = ConvGeom(tuple(t[1] for t in taps), tuple(0 for _ in taps), 2, 1)
+        return g, [t[2] for t in taps]
+
+
+def geom_conv(k: int, stride: int = 1, dilation: int = 1) -> ConvGeom:
+    """nn.Conv1d(k, stride, padding=(k-1)*d//2, dilation=d) (models.py:558, 689-699)."""
+    pad = (k - 1) * dilation // 2
+    offs = tuple(i * dilation - pad for i in range(k))
+    return ConvGeom(offs, tuple(0 for _ in offs), stride, 1)
+
+
+def geom_convt_k4s2p1() -> Tuple[ConvGeom, Tuple[int, ...]]:
+    """nn.ConvTranspose1d(k=4, s=2, p=1) (models.py:592, 881): o = 2i - 1 + k.
+    Even outputs use k=1 (i=m) and k=3 (i=m-1); odd outputs k=0 (i=m+1) and k=2 (i=m).
+    Returns the geometry and the kernel index each tap reads."""
+    return ConvGeom((-1, 0, 0, 1), (0, 0, 1, 1), 1, 2), (3, 1, 2, 0)
+
+
+def merged_dilated_taps(k: int, dilations: Sequence[int]) -> Tuple[ConvGeom, List[Tuple[int, int, int]]]:
+    """The 4 parallel dilated convs of MultiScaleDilatedConv1d (models.py:739-759) are linear
+    in x, so their softmax-weighted sum is ONE conv whose taps are the union of the branch
+    taps (28 taps -> 23 distinct offsets for k=7, d=(1,4,16,32)).  Returns the merged geometry
+    (stride filled in by the caller) and, for every (branch, k) pair, its merged tap index."""
+    pairs = []
+    offs = sorted({i * d - (k - 1) * d // 2 for d in dilations for i in range(k)})
+    index = {o: j for j, o in enumerate(offs)}
+    for b, d in enumerate(dilations):
+        for i in range(k):
+            pairs.append((b, i, index[i * d - (k - 1) * d // 2]))
+    return ConvGeom(tuple(offs), tuple(0 for _ in offs), 1, 1), pairs
+
+
+def conv_out_len(l_in: int, k: int, stride: int, dilation: int = 1) -> int:
+    pad = (k - 1) * dilation // 2
+    return (l_in + 2 * pad - dilation * (k - 1) - 1) // stride + 1
+
+
+# ---------------------------------------------------------------------------------------------
+# conv launchers
+# ---------------------------------------------------------------------------------------------
+def _desc(geom: ConvGeom, x1: Tensor, x2: Optional[Tensor], y: Tensor, res: Optional[Tensor], act: int = 0) -> ConvDesc:
+    if geom.n_taps > _lib.MAX_TAPS:
+        raise ValueError(f"{geom.n_taps} taps exceed UNET_MAX_TAPS={_lib.MAX_TAPS}")
+    d = ConvDesc()
+    d.dtype = _dt(x1)
+    d.n, d.l_in, d.c1 = x1.shape
+    d.x1_ld, d.x1_ns = x1.stride(1), x1.stride(0)
+    if x2 is not None:
+        if x2.shape[:2] != x1.shape[:2] or x2.dtype != x1.dtype:
+            raise ValueError("concat sources must agree in batch, length and dtype")
+        d.c2, d.x2_ld, d.x2_ns = x2.shape[2], x2.stride(1), x2.stride(0)
+    else:
+        d.c2, d.x2_ld, d.x2_ns = 0, 0, 0
+    d.l_out, d.c_out = y.shape[1], y.shape[2]
+    d.y_ld, d.y_ns = y.stride(1), y.stride(0)
+    if res is not None:
+        if res.shape != y.shape or res.dtype != y.dtype:
+            raise ValueError(f"residual {tuple(res.shape)}/{res.dtype} does not match output {tuple(y.shape)}/{y.dtype}")
+        d.res_ld, d.res_ns = res.stride(1), res.stride(0)
+    d.stride, d.up, d.n_taps = geom.stride, geom.up, geom.n_taps
+    for j, (o, r) in enumerate(zip(geom.offs, geom.phases)):
+        d.tap_off[j] = o
+        d.tap_phase[j] = r
+    d.act = act
+    return d
+
+
+def pack_weights(w: Tensor, dtype: int, *, transpose: bool, tap_src: Optional[Sequence[int]], n_taps: int,
+                 row_lo: int, rows: int, c1: int, c2: int) -> Tensor:
+    """w: fp32 [J, Cout, Ctot] (any strides).  transpose=False packs rows=co, K=ci (forward);
+    transpose=True packs rows=ci[row_lo:row_lo+rows], K=co (data gradient)."""
+    lib = _lib.load()
+    nbytes = lib.unet_conv1d_packed_bytes(dtype, n_taps, rows, c1, c2)
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    ts, s1, s2 = w.stride()
+    rs, cs = (s2, s1) if transpose else (s1, s2)
+    src = None
+    if tap_src is not None:
+        src = (C.c_int32 * n_taps)(*tap_src)
+    check(lib.unet_conv1d_pack(dtype, _p(w), ts, rs, cs, n_taps, src, row_lo, rows, 0, c1, c2, _p(out), _stream()),
+          "unet_conv1d_pack")
+    return out
+
+
+def conv_forward_raw(geom: ConvGeom, x1: Tensor, x2: Optional[Tensor], w_packed: Tensor, bias: Optional[Tensor],
+                     res: Optional[Tensor], l_out: int, c_out: int, act: int = 0) -> Tensor:
+    lib = _lib.load()
+    y = torch.empty((x1.shape[0], l_out, c_out), dtype=x1.dtype, device=x1.device)
+    d = _desc(geom, x1, x2, y, res, act)
+    check(lib.unet_conv1d_fwd(C.byref(d), _p(x1), _p(x2), _p(w_packed), _p(bias), _p(res), _p(y), _stream()),
+          "unet_conv1d_fwd")
+    return y
+
+
+class ConvFn(torch.autograd.Function):
+    """y = conv(geom; [x1 | x2], w[J, Cout, C1+C2], bias) (+ res).  See include/unet_hip.h."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, bias, res, geom: ConvGeom, l_out: int):
+        _need_cuda(x1)
+        x1 = _nlc_ok(x1)
+        x2 = _nlc_ok(x2) if x2 is not None else None
+        res = _nlc_ok(res) if res is not None else None
+        dt = _dt(x1)
+        c1 = x1.shape[2]
+        c2 = x2.shape[2] if x2 is not None else 0
+        j, c_out, ctot = w.shape
+        if j != geom.n_taps or ctot != c1 + c2:
+            raise ValueError(f"weight {tuple(w.shape)} does not fit taps={geom.n_taps}, channels={c1}+{c2}")
+        wf = w.detach()
+        if wf.dtype != torch.float32:
+            wf = wf.float()
+        wp = pack_weights(wf, dt, transpose=False, tap_src=None, n_taps=j, row_lo=0, rows=c_out, c1=c1, c2=c2)
+        b = _f32c(bias) if bias is not None else None
+        y = conv_forward_raw(geom, x1, x2, wp, b, res, l_out, c_out)
+        ctx.geom, ctx.l_out = geom, l_out
+        ctx.has_x2, ctx.has_bias, ctx.has_res = x2 is not None, bias is not None, res is not None
+        ctx.w_dtype = w.dtype
+        ctx.save_for_backward(x1, x2, wf)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x1, x2, wf = ctx.saved_tensors
+        geom: ConvGeom = ctx.geom
+        dy = dy.contiguous()
+        dt = _dt(dy)
+        n, l_in, c1 = x1.shape
+        c2 = x2.shape[2] if x2 is not None else 0
+        j, c_out, ctot = wf.shape
+        dx1 = dx2 = dw = db = dres = None
+        if ctx.has_res and ctx.needs_input_grad[4]:
+            dres = dy
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = colsum(dy)
+        if ctx.needs_input_grad[2]:
+            y_like = dy
+            d = _desc(geom, x1, x2, y_like, None)
+            ws_bytes = lib.unet_conv1d_wgrad_workspace_bytes(C.byref(d))
+            ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=dy.device)
+            dw = torch.empty((j, c_out, ctot), dtype=torch.float32, device=dy.device)
+            check(lib.unet_conv1d_wgrad(C.byref(d), _p(x1), _p(x2), _p(dy), _p(dw), _p(ws), ws_bytes, _stream()),
+                  "unet_conv1d_wgrad")
+            if ctx.w_dtype != torch.float32:
+                dw = dw.to(ctx.w_dtype)
+        need1, need2 = ctx.needs_input_grad[0], ctx.has_x2 and ctx.needs_input_grad[1]
+        if need1 or need2:
+            gd, src = geom.dgrad()
+            if need1:
+                wp = pack_weights(wf, dt, transpose=True, tap_src=src, n_taps=j, row_lo=0, rows=c1, c1=c_out, c2=0)
+                dx1 = conv_forward_raw(gd, dy, None, wp, None, None, l_in, c1)
+            if need2:
+                wp = pack_weights(wf, dt, transpose=True, tap_src=src, n_taps=j, row_lo=c1, rows=c2, c1=c_out, c2=0)
+                dx2 = conv_forward_raw(gd, dy, None, wp, None, None, l_in, c2)
+        return dx1, dx2, dw, db, dres, None, None
+
+
+def conv(x1: Tensor, w: Tensor, bias: Optional[Tensor], geom: ConvGeom, l_out: int, x2: Optional[Tensor] = None,
+         res: Optional[Tensor] = None) -> Tensor:
+    return ConvFn.apply(x1, x2, w, bias, res, geom, l_out)
+
+
+# ---------------------------------------------------------------------------------------------
+# streaming kernels
+# ---------------------------------------------------------------------------------------------
+def _dims(x: Tensor):
+    n, rows, c = x.shape
+    return n, rows, c
+
+
+def _part_buf(x: Tensor, k: int = 1):
+    n, rows, c = x.shape
+    return [torch.empty((n, parts(rows), c), dtype=torch.float32, device=x.device) for _ in range(k)]
+
+
+def colsum(x: Tensor) -> Tensor:
+    """sum over windows and rows -> [C] fp32"""
+    lib = _lib.load()
+    x = x.contiguous()
+    (buf,) = _part_buf(x)
+    check(lib.unet_colsum(_dt(x), _p(x), _p(buf), *_dims(x), _stream()), "unet_colsum")
+    return buf.sum(dim=(0, 1))
+
+
+def rowstats(y: Tensor) -> Tuple[Tensor, Tensor]:
+    """per-(window, channel) sum and sum of squares over rows -> two [N, C] fp64 tensors"""
+    lib = _lib.load()
+    s1, s2 = _part_buf(y, 2)
+    check(lib.unet_rowstats(_dt(y), _p(y), _p(s1), _p(s2), *_dims(y), _stream()), "unet_rowstats")
+    return s1.double().sum(dim=1), s2.double().sum(dim=1)
+
+
+class AffineActFn(torch.autograd.Function):
+    """z = act(a*y + b) with per-(window, channel) a, b; optional pooled sum over rows.
+
+    Backward uses a "normalisation set" description so one pair of kernels serves BatchNorm
+    (train/eval), InstanceNorm, GroupNorm and plain activations:
+        dy = ca*g + cb*y + cc,   g = (dz + dpool) * act'(a*y + b)
+    with ca/cb/cc computed from the two reductions sum_t g and sum_t g*y.
+    """
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, stats, act_id: int, want_pool: bool):
+        # stats: None (identity affine) or dict(mean[N,C], rstd[N,C], mode, groups, count, coupled)
+        lib = _lib.load()
+        _need_cuda(y)
+        y = y.contiguous()
+        n, rows, c = y.shape
+        dev = y.device
+        if stats is None:
+            a = torch.ones((n, c), dtype=torch.float32, device=dev)
+            b = torch.zeros((n, c), dtype=torch.float32, device=dev)
+        else:
+            g = gamma.detach().double() if gamma is not None else torch.ones(c, dtype=torch.float64, device=dev)
+            bt = beta.detach().double() if beta is not None else torch.zeros(c, dtype=torch.float64, device=dev)
+            a64 = stats["rstd"] * g[None, :]
+            a = a64.float().contiguous()
+            b = (bt[None, :] - stats["mean"] * a64).float().contiguous()
+        z = torch.empty_like(y)
+        pool = None
+        pbuf = None
+        if want_pool:
+            (pbuf,) = _part_buf(y)
+        check(lib.unet_affine_act_fwd(_dt(y), _p(y), _p(a), _p(b), act_id, _p(z), _p(pbuf), n, rows, c, _stream()),
+              "unet_affine_act_fwd")
+        if want_pool:
+            pool = pbuf.sum(dim=1)
+        ctx.stats, ctx.act_id, ctx.want_pool = stats, act_id, want_pool
+        ctx.has_affine = gamma is not None
+        ctx.save_for_backward(y, a, b, gamma)
+        if want_pool:
+            return z, pool
+        return z
+
+    @staticmethod
+    def backward(ctx, dz, dpool=None):
+        lib = _lib.load()
+        y, a, b, gamma = ctx.saved_tensors
+        stats = ctx.stats
+        n, rows, c = y.shape
+        dz = dz.contiguous()
+        dp = _f32c(dpool) if (ctx.want_pool and dpool is not None) else None
+        coupled = stats is not None and stats["coupled"]
+        need_param = ctx.has_affine and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        dgamma = dbeta = None
+        if coupled or need_param:
+            g1p, g2p = _part_buf(y, 2)
+            check(lib.unet_affine_act_bwd_reduce(_dt(y), _p(y), _p(dz), _p(dp), _p(a), _p(b), ctx.act_id, _p(g1p),
+                                                 _p(g2p), n, rows, c, _stream()), "unet_affine_act_bwd_reduce")
+            g1 = g1p.double().sum(dim=1)
+            g2 = g2p.double().sum(dim=1)
+        if stats is None:
+            ca, cb, cc = a, torch.zeros_like(a), torch.zeros_like(a)
+        else:
+            mean, rstd = stats["mean"], stats["rstd"]
+            gm = gamma.detach().double() if gamma is not None else torch.ones(c, dtype=torch.float64, device=y.device)
+            if coupled or need_param:
+                gy = rstd * (g2 - mean * g1)  # sum_t g * yhat
+            if need_param:
+                dgamma = gy.sum(dim=0).to(gamma.dtype)
+                dbeta = g1.sum(dim=0).to(gamma.dtype)
+            if coupled:
+                red = stats["reduce"]
+                cnt = stats["count"]
+                m1 = red(gm[None, :] * g1) / cnt
+                m2 = red(gm[None, :] * gy) / cnt
+                ca = a
+                cb = (-rstd * rstd * m2).float().contiguous()
+                cc = (-rstd * m1 + rstd * rstd * mean * m2).float().contiguous()
+            else:
+                ca, cb, cc = a, torch.zeros_like(a), torch.zeros_like(a)
+        dy = None
+        if ctx.needs_input_grad[0]:
+            dy = torch.empty_like(y)
+            check(lib.unet_affine_act_bwd_apply(_dt(y), _p(y), _p(dz), _p(dp), _p(a), _p(b), ctx.act_id, _p(ca),
+                                                _p(cb), _p(cc), _p(dy), n, rows, c, _stream()),
+                  "unet_affine_act_bwd_apply")
+        return dy, dgamma, dbeta, None, None, None
+
+
+def activation(x: Tensor, act_id: int) -> Tensor:
+    return AffineActFn.apply(x, None, None, None, act_id, False)
+
+
+class ScaleFn(torch.autograd.Function):
+    """out = x * s[n, c]  (SE excite, models.py:662)"""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        lib = _lib.load()
+        _need_cuda(x)
+        x = x.contiguous()
+        sf = _f32c(s)
+        out = torch.empty_like(x)
+        check(lib.unet_scale_fwd(_dt(x), _p(x), _p(sf), _p(out), *_dims(x), _stream()), "unet_scale_fwd")
+        ctx.save_for_backward(x, sf)
+        ctx.s_dtype = s.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, sf = ctx.saved_tensors
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        (dsp,) = _part_buf(x)
+        check(lib.unet_scale_bwd(_dt(x), _p(x), _p(dout), _p(sf), _p(dx), _p(dsp), *_dims(x), _stream()),
+              "unet_scale_bwd")
+        return dx, dsp.sum(dim=1).to(ctx.s_dtype)
+
+
+class FilmSoftmaxFn(torch.autograd.Function):
+    """h = softmax_c(q * kk[n, :]) * v[n, :]  (models.py:514-515; kk already holds C^-1/2)"""
+
+    @staticmethod
+    def forward(ctx, q, kk, v):
+        lib = _lib.load()
+        _need_cuda(q)
+        q = q.contiguous()
+        kf, vf = _f32c(kk), _f32c(v)
+        h = torch.empty_like(q)
+        check(lib.unet_film_softmax_fwd(_dt(q), _p(q), _p(kf), _p(vf), _p(h), *_dims(q), _stream()),
+              "unet_film_softmax_fwd")
+        ctx.save_for_backward(q, kf, vf)
+        ctx.kdt, ctx.vdt = kk.dtype, v.dtype
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        lib = _lib.load()
+        q, kf, vf = ctx.saved_tensors
+        dh = dh.contiguous()
+        dq = torch.empty_like(q)
+        dkp, dvp = _part_buf(q, 2)
+        check(lib.unet_film_softmax_bwd(_dt(q), _p(q), _p(dh), _p(kf), _p(vf), _p(dq), _p(dkp), _p(dvp), *_dims(q),
+                                        _stream()), "unet_film_softmax_bwd")
+        return dq, dkp.sum(dim=1).to(ctx.kdt), dvp.sum(dim=1).to(ctx.vdt)
+
+
+class GatedAddFn(torch.autograd.Function):
+    """out = res + g[n, c] * o  (models.py:517)"""
+
+    @staticmethod
+    def forward(ctx, res, o, g):
+        lib = _lib.load()
+        _need_cuda(o)
+        res, o = res.contiguous(), o.contiguous()
+        gf = _f32c(g)
+        out = torch.empty_like(o)
+        check(lib.unet_gated_add_fwd(_dt(o), _p(res), _p(o), _p(gf), _p(out), *_dims(o), _stream()),
+              "unet_gated_add_fwd")
+        ctx.save_for_backward(o, gf)
+        ctx.gdt = g.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        o, gf = ctx.saved_tensors
+        dout = dout.contiguous()
+        d_o = torch.empty_like(o)
+        (dgp,) = _part_buf(o)
+        check(lib.unet_gated_add_bwd(_dt(o), _p(o), _p(dout), _p(gf), _p(d_o), _p(dgp), *_dims(o), _stream()),
+              "unet_gated_add_bwd")
+        return dout, d_o, dgp.sum(dim=1).to(ctx.gdt)
+
+
+# ---------------------------------------------------------------------------------------------
+# model boundary: NCL <-> NLC with the z-score of models.py:3235 fused into the way in
+# ---------------------------------------------------------------------------------------------
+def ncl_moments(x: Tensor, eps: float) -> Tuple[Tensor, Tensor]:
+    lib = _lib.load()
+    n, c, t = x.shape
+    mean = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    check(lib.unet_ncl_moments(_dt(x), _p(x), _p(mean), _p(rstd), n, c, t, eps, _stream()), "unet_ncl_moments")
+    return mean, rstd
+
+
+class ZScoreInFn(torch.autograd.Function):
+    """x_nlc[n, t, c] = (ob[n, c, t] - mean) / (std_unbiased + 1e-8)   in the compute dtype"""
+
+    @staticmethod
+    def forward(ctx, ob, out_dtype):
+        lib = _lib.load()
+        _need_cuda(ob)
+        ob = ob.contiguous()
+        n, c, t = ob.shape
+        mean, rstd = ncl_moments(ob, 1e-8)
+        x = torch.empty((n, t, c), dtype=out_dtype, device=ob.device)
+        check(lib.unet_ncl_to_nlc(_dt(ob), _dt(x), _p(ob), _p(mean), _p(rstd), _p(x), n, c, t, _stream()),
+              "unet_ncl_to_nlc")
+        ctx.save_for_backward(x, rstd)
+        ctx.in_dtype = ob.dtype
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        lib = _lib.load()
+        x, rstd = ctx.saved_tensors
+        dx = dx.contiguous()
+        n, t, c = x.shape
+        ones = torch.ones((n, c), dtype=torch.float32, device=x.device)
+        zeros = torch.zeros_like(ones)
+        g1p, g2p = _part_buf(x, 2)
+        check(lib.unet_affine_act_bwd_reduce(_dt(x), _p(x), _p(dx), _p(None), _p(ones), _p(zeros), 0, _p(g1p), _p(g2p),
+                                             n, t, c, _stream()), "unet_affine_act_bwd_reduce")
+        g1 = g1p.double().sum(dim=1)
+        g2 = g2p.double().sum(dim=1)          # sum_t g * xhat
+        r = rstd.double()
+        sigma = 1.0 / r - 1e-8
+        ga = rstd
+        gb = (-g2 / (max(t - 1, 1) * sigma)).float().contiguous()
+        be = (-r * g1 / t).float().contiguous()
+        dob = torch.empty((n, c, t), dtype=ctx.in_dtype, device=x.device)
+        check(lib.unet_nlc_to_ncl(_dt(x), _dt(dob), _p(dx), _p(x), _p(ga), _p(gb), _p(be), _p(dob), n, c, t, _stream()),
+              "unet_nlc_to_ncl")
+        return dob, None
+
+
+class ToNCLFn(torch.autograd.Function):
+    """plain layout change NLC -> NCL (the model's output side)"""
+
+    @staticmethod
+    def forward(ctx, x, out_dtype):
+        lib = _lib.load()
+        _need_cuda(x)
+        x = x.contiguous()
+        n, t, c = x.shape
+        y = torch.empty((n, c, t), dtype=out_dtype, device=x.device)
+        check(lib.unet_nlc_to_ncl(_dt(x), _dt(y), _p(x), _p(None), _p(None), _p(None), _p(None), _p(y), n, c, t,
+                                  _stream()), "unet_nlc_to_ncl")
+        ctx.x_dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = dy.contiguous()
+        n, c, t = dy.shape
+        dx = torch.empty((n, t, c), dtype=ctx.x_dtype, device=dy.device)
+        check(lib.unet_ncl_to_nlc(_dt(dy), _dt(dx), _p(dy), _p(None), _p(None), _p(dx), n, c, t, _stream()),
+              "unet_ncl_to_nlc")
+        return dx, None
+
+
+class ToNLCFn(torch.autograd.Function):
+    """plain layout change NCL -> NLC (used when a block is called directly with an NCL tensor)"""
+
+    @staticmethod
+    def forward(ctx, x, out_dtype):
+        lib = _lib.load()
+        _need_cuda(x)
+        x = x.contiguous()
+        n, c, t = x.shape
+        y = torch.empty((n, t, c), dtype=out_dtype, device=x.device)
+        check(lib.unet_ncl_to_nlc(_dt(x), _dt(y), _p(x), _p(None), _p(None), _p(y), n, c, t, _stream()),
+              "unet_ncl_to_nlc")
+        ctx.x_dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        dy = dy.contiguous()
+        n, t, c = dy.shape
+        dx = torch.empty((n, c, t), dtype=ctx.x_dtype, device=dy.device)
+        check(lib.unet_nlc_to_ncl(_dt(dy), _dt(dx), _p(dy), _p(None), _p(None), _p(None), _p(None), _p(dx), n, c, t,
+                                  _stream()), "unet_nlc_to_ncl")
+        return dx, None
