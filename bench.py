@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Headline benchmark: train windows/sec of the CondUNet1D hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): the train.py/LOSO default model
+(in=out=32, base=256, conv_type=modern, attention none, gelu, skip add, batch norm,
+cross_attn_gated FiLM; 41,966,772 parameters), synthetic N(0,1) windows of 32 ch x 4096 samples,
+64 windows per GPU, bf16 kernels with fp32 master weights.  One step = forward + L1 on the
+[500:4500] crop + backward + bucketed gradient all-reduce (N>1) + grad-clip 5.0 + AdamW step,
+i.e. everything the reference's train_epoch does per batch (train.py:1395-1560).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- the dominant kernel (implicit-GEMM conv forward/data-grad on bf16 MFMA), timed
+                  live with HIP events around every launch of the timed region
+  cpu_baseline -- the CPU oracle (oracle/condunet_oracle.py, a port of the reference's algorithm
+                  in torch fp32) timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+CONFIG_B = dict(in_channels=32, out_channels=32, base=256, conv_type="modern", attention_type="none",
+                activation="gelu", skip_type="add", norm_type="batch", cond_mode="cross_attn_gated",
+                n_downsample=2)
+T = 4096
+CROP = (500, 4500)
+GFLOP_PER_WINDOW_FWD = 122.339       # algorithmic conv FLOPs, config B
+BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="windows per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-windows", type=int, default=2)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(n_windows: int):
+    """Oracle (CPU port of the reference path) on a bounded sample of the same workload."""
+    from oracle import condunet_oracle as O
+    threads = torch.get_num_threads()
+    sd = O.init_state_dict(CONFIG_B, seed=0)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    run_sd = dict(sd)
+    run_sd.update(leaves)
+    g = torch.Generator().manual_seed(0)
+    ob = torch.randn(n_windows, 32, T, generator=g)
+    tgt = torch.randn(n_windows, 32, T, generator=g)
+    ids = torch.zeros(n_windows, dtype=torch.long)
+    t0 = time.perf_counter()
+    loss = O.train_step_loss(run_sd, CONFIG_B, ob, tgt, odor_ids=ids)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": n_windows / dt, "unit": "windows/s", "cores": threads, "kind": "port",
+            "sample": f"1 fwd+bwd step of config B on {n_windows} windows (32ch x {T}), fp32, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import unet_amd
+    from unet_amd import ops
+    from unet_amd.dp import BucketedGradAllReduce, broadcast_parameters
+
+    torch.manual_seed(0)
+    model = unet_amd.CondUNet1D(**CONFIG_B)
+    with torch.no_grad():  # the reference zero-initialises outc; give it values so backward is not trivially zero
+        model.outc.weight.normal_(0, 0.02)
+    model = model.to(dev)
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model.set_compute_dtype(cdt)
+    model.train()
+    broadcast_parameters(model)
+    n_params = sum(p.numel() for p in model.parameters())
+
+    reducer = BucketedGradAllReduce(model.parameters())
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.7595905764360957, 0.920298282605139),
+                            weight_decay=0.0, fused=True)  # train.py:183-193
+
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    B = args.batch
+    ob = torch.randn(B, 32, T, device=dev, generator=g).to(cdt)
+    tgt = torch.randn(B, 32, T, device=dev, generator=g)
+    tgt = (tgt - tgt.mean(-1, keepdim=True)) / tgt.std(-1, keepdim=True).clamp(min=1e-6)  # train.py:476-495
+    ids = torch.zeros(B, dtype=torch.long, device=dev)
+
+    def step():
+        reducer.zero_grad()
+        pred = model(ob, ids)
+        loss = F.l1_loss(pred[..., CROP[0]:CROP[1]].float(), tgt[..., CROP[0]:CROP[1]])
+        loss.backward()
+        reducer.finish()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)  # train.py:1553 GRAD_CLIP
+        opt.step()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if not args.no_kernel_timing:
+        ops.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    windows = B * world * args.steps
+    value = windows / dt
+    out = {
+        "metric": "train windows/sec (fwd+bwd)", "value": value, "unit": "windows/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic N(0,1) windows, random-init weights (reference init, seed 0)",
+        "config": {"workload": "config B: CondUNet1D train.py/LOSO default (base=256, modern 4x dilated k7 + SE, FiLM, "
+                               "skip add, BN), 32ch x 4096 windows, 64 windows/GPU, fwd + L1[500:4500] + bwd + "
+                               "grad all-reduce + clip 5.0 + AdamW", "windows_per_gpu": B, "params": n_params,
+                   "parallelism": f"dp{world}"},
+        "final_loss": float(loss.item()),
+        "model_tflops_algorithmic": value * 3 * GFLOP_PER_WINDOW_FWD / 1e3,
+        "frac_of_bf16_mfma_peak_end_to_end": value * 3 * GFLOP_PER_WINDOW_FWD / 1e3 / (BF16_DENSE_PEAK_TFLOPS * world),
+    }
+    if prof:
+        agg = {}
+        for kind, flops, e0, e1 in prof:
+            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        kern = {k: {"launches": v[2], "avg_us": 1e6 * v[1] / v[2], "tflops_algorithmic": v[0] / v[1] / 1e12,
+                    "ms_per_step": 1e3 * v[1] / args.steps} for k, v in agg.items()}
+        dom = agg["conv_fwd"]
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_fwd_kernel<bf16> (implicit-GEMM conv forward + data-grad)",
+                           "achieved": dom[0] / dom[1] / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": dom[0] / dom[1] / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                           "avg_launch_us": 1e6 * dom[1] / dom[2], "launches": dom[2]}
+        out["kernels"] = kern
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_windows)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

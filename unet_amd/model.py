@@ -280,7 +280,7 @@ class MultiScaleDilatedConv1d(nn.Module):
             for d in dilations])
         self.scale_weights = nn.Parameter(torch.ones(self.n_scales) / self.n_scales)
         g, pairs = ops.merged_dilated_taps(kernel_size, self.dilations)
-        self._geom = ops.ConvGeom(g.offs, g.phases, stride, 1)
+        self._geom = ops.ConvGeom(g.offs, g.phases, stride, 1, g.alg_scale)
         self.register_buffer("_tap_index", torch.tensor([p[2] for p in pairs], dtype=torch.long), persistent=False)
 
     def effective_weights(self) -> Tuple[Tensor, Tensor]:

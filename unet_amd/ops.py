@@ -58,6 +58,27 @@ def _f32c(t: Tensor) -> Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
+# When set to a list, every MFMA conv launch appends (kind, algorithmic FLOPs, start event, end event);
+# bench.py uses it to time the dominant kernel live, on the stream the kernels are launched on.
+PROFILE: Optional[list] = None
+
+
+class _Timed:
+    def __init__(self, kind: str, flops: float):
+        self.on = PROFILE is not None
+        if self.on:
+            self.rec = (kind, flops, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    def __enter__(self):
+        if self.on:
+            self.rec[2].record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.rec[3].record()
+            PROFILE.append(self.rec)
+
+
 def parts(rows: int) -> int:
     return int(_lib.load().unet_parts(rows))
 
@@ -72,13 +93,16 @@ class ConvGeom:
     phases: Tuple[int, ...]
     stride: int = 1
     up: int = 1
+    alg_scale: float = 1.0  # reference-algorithm taps / executed taps (28/23 for the merged dilated conv)
 
     @property
     def n_taps(self) -> int:
         return len(self.offs)
 
-    def out_len(self, l_in: int, k_eff_pad: Optional[Tuple[int, int, int]] = None) -> int:
-        raise NotImplementedError
+    def alg_flops(self, n: int, l_out: int, c_out: int, c_in: int) -> float:
+        """FLOPs of the reference's algorithm for one launch: 2*Cin*Cout per (tap, output row it feeds)."""
+        rows = sum((l_out - r + self.up - 1) // self.up for r in self.phases)
+        return 2.0 * n * c_out * c_in * rows * self.alg_scale
 
     def dgrad(self) -> Tuple["ConvGeom", List[int]]:
         """Geometry of the data gradient and, for each of ITS taps, the forward tap it uses."""
@@ -95,11 +119,11 @@ class ConvGeom:
                 raise ValueError("unsupported geometry")
         taps.sort(key=lambda t: (t[0], t[1]))
         if self.up == 1 and self.stride == 1:
-            g = ConvGeom(tuple(t[1] for t in taps), tuple(0 for _ in taps), 1, 1)
+            g = ConvGeom(tuple(t[1] for t in taps), tuple(0 for _ in taps), 1, 1, self.alg_scale)
         elif self.up == 1 and self.stride == 2:
-            g = ConvGeom(tuple(t[1] for t in taps), tuple(t[0] for t in taps), 1, 2)
+            g = ConvGeom(tuple(t[1] for t in taps), tuple(t[0] for t in taps), 1, 2, self.alg_scale)
         else:
-            g = ConvGeom(tuple(t[1] for t in taps), tuple(0 for _ in taps), 2, 1)
+            g = ConvGeom(tuple(t[1] for t in taps), tuple(0 for _ in taps), 2, 1, self.alg_scale)
         return g, [t[2] for t in taps]
 
 
@@ -128,7 +152,7 @@ def merged_dilated_taps(k: int, dilations: Sequence[int]) -> Tuple[ConvGeom, Lis
     for b, d in enumerate(dilations):
         for i in range(k):
             pairs.append((b, i, index[i * d - (k - 1) * d // 2]))
-    return ConvGeom(tuple(offs), tuple(0 for _ in offs), 1, 1), pairs
+    return ConvGeom(tuple(offs), tuple(0 for _ in offs), 1, 1, len(pairs) / len(offs)), pairs
 
 
 def conv_out_len(l_in: int, k: int, stride: int, dilation: int = 1) -> int:
@@ -188,8 +212,9 @@ def conv_forward_raw(geom: ConvGeom, x1: Tensor, x2: Optional[Tensor], w_packed:
     lib = _lib.load()
     y = torch.empty((x1.shape[0], l_out, c_out), dtype=x1.dtype, device=x1.device)
     d = _desc(geom, x1, x2, y, res, act)
-    check(lib.unet_conv1d_fwd(C.byref(d), _p(x1), _p(x2), _p(w_packed), _p(bias), _p(res), _p(y), _stream()),
-          "unet_conv1d_fwd")
+    with _Timed("conv_fwd", geom.alg_flops(d.n, l_out, c_out, d.c1 + d.c2)):
+        check(lib.unet_conv1d_fwd(C.byref(d), _p(x1), _p(x2), _p(w_packed), _p(bias), _p(res), _p(y), _stream()),
+              "unet_conv1d_fwd")
     return y
 
 
@@ -241,8 +266,9 @@ class ConvFn(torch.autograd.Function):
             ws_bytes = lib.unet_conv1d_wgrad_workspace_bytes(C.byref(d))
             ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=dy.device)
             dw = torch.empty((j, c_out, ctot), dtype=torch.float32, device=dy.device)
-            check(lib.unet_conv1d_wgrad(C.byref(d), _p(x1), _p(x2), _p(dy), _p(dw), _p(ws), ws_bytes, _stream()),
-                  "unet_conv1d_wgrad")
+            with _Timed("conv_wgrad", geom.alg_flops(n, dy.shape[1], c_out, ctot)):
+                check(lib.unet_conv1d_wgrad(C.byref(d), _p(x1), _p(x2), _p(dy), _p(dw), _p(ws), ws_bytes, _stream()),
+                      "unet_conv1d_wgrad")
             if ctx.w_dtype != torch.float32:
                 dw = dw.to(ctx.w_dtype)
         need1, need2 = ctx.needs_input_grad[0], ctx.has_x2 and ctx.needs_input_grad[1]
