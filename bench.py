@@ -131,9 +131,12 @@ def main():
     sync()
     if not args.no_kernel_timing:
         ops.PROFILE = []
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         loss = step()
+        evs[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
@@ -154,6 +157,7 @@ def main():
                                "grad all-reduce + clip 5.0 + AdamW", "windows_per_gpu": B, "params": n_params,
                    "parallelism": f"dp{world}"},
         "final_loss": float(loss.item()),
+        "ms_each_step": [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(args.steps)],
         "model_tflops_algorithmic": value * 3 * GFLOP_PER_WINDOW_FWD / 1e3,
         "frac_of_bf16_mfma_peak_end_to_end": value * 3 * GFLOP_PER_WINDOW_FWD / 1e3 / (BF16_DENSE_PEAK_TFLOPS * world),
     }

@@ -124,5 +124,27 @@ def main():
         print(f"{name}: loss={loss.item():.6f} keys={len(sd0)} -> {os.path.getsize(path)/1e3:.0f} kB")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--init-only" not in sys.argv:
     main()
+
+
+def init_checksums():
+    """Per-tensor (sum, abs-sum) of the reference's freshly constructed models at seed 7 -- pins that
+    unet_amd consumes the init RNG stream in the same order (same seed -> same initial weights)."""
+    sys.path.insert(0, REF)
+    import models as ref
+    blob = {}
+    for tag, kw in (("A", {}), ("B", dict(base=32, conv_type="modern", attention_type="none", activation="gelu")),
+                    ("B2", dict(base=32, conv_type="modern", skip_type="concat", use_adaptive_scaling=True,
+                                in_channels=16, out_channels=8))):
+        torch.manual_seed(7)
+        m = ref.CondUNet1D(**kw)
+        for k, v in m.state_dict().items():
+            if v.is_floating_point():
+                blob[f"{tag}/{k}"] = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+    np.savez_compressed(os.path.join(OUT, "init_checksums.npz"), **blob)
+    print("init_checksums:", len(blob), "tensors")
+
+
+if __name__ == "__main__":
+    init_checksums()

@@ -1,0 +1,101 @@
+"""Data-parallel gradient exchange (unet_amd/dp.py) on 2 CPU ranks over gloo: bucketed, hook-driven
+all-reduce must equal the average of the per-rank gradients (what DDP computes, train.py:2161)
+including parameters that receive no gradient on a step."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                               torch.nn.Linear(16, 3))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unet_amd.dp import BucketedGradAllReduce, broadcast_parameters
+    model = _model()
+    unused = torch.nn.Parameter(torch.ones(5))           # never used in forward
+    params = list(model.parameters()) + [unused]
+    if rank == 1:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)                              # ranks start different ...
+    broadcast_parameters(model)                          # ... and are made equal to rank 0
+    red = BucketedGradAllReduce(params, bucket_bytes=600)  # tiny buckets -> several messages
+    assert len(red.buckets) > 2
+    out = []
+    for step in range(2):
+        red.zero_grad()
+        torch.manual_seed(100 + 10 * step + rank)
+        x = torch.randn(4, 6)
+        model(x).pow(2).sum().backward()
+        red.finish()
+        out.append([p.grad.numpy().copy() for p in params])
+    q.put((rank, out, [p.detach().numpy().copy() for p in model.parameters()]))  # by value
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_matches_mean_of_rank_gradients():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, grads, weights = q.get(timeout=120)
+        res[rank] = ([[torch.from_numpy(g) for g in st] for st in grads], [torch.from_numpy(w) for w in weights])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # every rank holds the same weights and the same reduced gradients
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+    for step in range(2):
+        for a, b in zip(res[0][0][step], res[1][0][step]):
+            assert torch.allclose(a, b, atol=1e-7)
+    # and they equal the mean of single-process gradients
+    for step in range(2):
+        expect = None
+        for rank in range(world):
+            model = _model()
+            torch.manual_seed(100 + 10 * step + rank)
+            x = torch.randn(4, 6)
+            model(x).pow(2).sum().backward()
+            g = [p.grad.clone() for p in model.parameters()]
+            expect = g if expect is None else [e + gi for e, gi in zip(expect, g)]
+        expect = [e / world for e in expect]
+        got = res[0][0][step]
+        for e, gi in zip(expect, got[:-1]):
+            assert torch.allclose(e, gi, atol=1e-6)
+        assert float(got[-1].abs().max()) == 0.0      # unused parameter: zeros, still reduced
+
+
+def test_single_process_is_a_no_op():
+    from unet_amd.dp import BucketedGradAllReduce
+    model = _model()
+    red = BucketedGradAllReduce(model.parameters())
+    red.zero_grad()
+    model(torch.randn(3, 6)).sum().backward()
+    red.finish()
+    ref = _model()
+    torch.manual_seed(0)
+    assert all(p.grad is not None for p in model.parameters())
+    assert red.world == 1

@@ -36,10 +36,19 @@ struct ConvK {
   int ptiles[2];
   int pbeg[3];
   int mcount[2];
-  int omin[2], omax[2];
+  // LDS image of the input halo tile, per output phase: up to two row segments (input-row parity
+  // classes when stride == 2, so that every tap reads LDS rows with unit stride).
+  // segment c holds input rows  stride*(m0 + seg_q0[ph][c] + i) + c,  i in [0, seg_rows[ph][c])
+  int seg_rows[2][2];
+  int seg_q0[2][2];
+  int x1_fast, x2_fast;  // 16-byte aligned rows and channel count a multiple of the chunk: LDS-DMA staging
   int x1_vec, x2_vec, y_vec, res_vec;
-  int tap_off[UNET_MAX_TAPS];
+  int xdb;               // input tile double-buffered
+  int xbytes;            // bytes of one input tile buffer (multiple of 1 KiB)
+  int tap_row[UNET_MAX_TAPS];  // LDS row that local output position 0 reads for this tap
 };
+
+__device__ const u32x4 g_zero_chunk = {0u, 0u, 0u, 0u};  // source of padding rows for LDS-DMA staging
 
 template <bool F32> struct Mma;
 template <> struct Mma<false> {
@@ -65,6 +74,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 template <bool F32, int BN>
 __global__ __launch_bounds__(THREADS, 2) void conv_fwd_kernel(const ConvK p) {
   typedef typename Elem<F32>::T T;
+  constexpr int ES = Elem<F32>::SIZE;
   constexpr int EPC = Elem<F32>::EPC;
   constexpr int KC = EPC * 8;          // K elements per 128-byte LDS row
   constexpr int NI = BN / 32;          // 16-wide position fragments per wave
@@ -73,7 +83,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv_fwd_kernel(const ConvK p) {
   char* wbuf = smem;
   char* xbuf = smem + 2 * WTILE_BYTES;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, lq = lane >> 4;
 
@@ -90,9 +101,10 @@ __global__ __launch_bounds__(THREADS, 2) void conv_fwd_kernel(const ConvK p) {
   const int m0 = pt * BN;
   const int tb = p.pbeg[phase];
   const int nt = p.pbeg[phase + 1] - tb;
-  const int omin = p.omin[phase];
-  const int R = p.stride * (BN - 1) + p.omax[phase] - omin + 1;
-  const int rowbase = p.stride * m0 + omin;
+  const int rows0 = p.seg_rows[phase][0], rows1 = p.seg_rows[phase][1];
+  const int R = rows0 + rows1;
+  const int g0a = p.stride * (m0 + p.seg_q0[phase][0]);       // input row of LDS row 0 (segment 0)
+  const int g0b = p.stride * (m0 + p.seg_q0[phase][1]) + 1;   // input row of LDS row rows0 (segment 1)
 
   f32x4 acc[4][NI];
 #pragma unroll
@@ -100,7 +112,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_fwd_kernel(const ConvK p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- staging helpers ---------------------------------------------------------------------
+  // ---- staging ------------------------------------------------------------------------------
   auto issue_w = [&](int step, int buf) {
     const int kc = step / nt, j = step - kc * nt;
     const char* tile = p.wp + ((size_t)((tb + j) * p.mtiles + mt) * p.kctot + kc) * WTILE_BYTES;
@@ -114,28 +126,50 @@ __global__ __launch_bounds__(THREADS, 2) void conv_fwd_kernel(const ConvK p) {
     }
   };
 
-  auto stage_x = [&](int kc) {
-    const char* src; int ld, csrc, cbase, vec; long long ns;
-    if (kc < p.kc1) { src = p.x1; ld = p.x1_ld; csrc = p.c1; cbase = kc * KC; ns = p.x1_ns; vec = p.x1_vec; }
-    else { src = p.x2; ld = p.x2_ld; csrc = p.c2; cbase = (kc - p.kc1) * KC; ns = p.x2_ns; vec = p.x2_vec; }
+  // input halo tile of K-chunk kc -> LDS buffer `buf`.  Fast path: LDS-DMA, 8 rows (1 KiB) per
+  // wave-instruction; the chunk swizzle is applied on the per-lane SOURCE address and padding /
+  // out-of-range chunks read a 16-byte zero constant.  Slow path (odd channel counts, unaligned
+  // views): through registers.
+  auto issue_x = [&](int kc, int buf) {
+    const char* src; int ld, csrc, cbase, fast, vec; long long ns;
+    if (kc < p.kc1) { src = p.x1; ld = p.x1_ld; csrc = p.c1; cbase = kc * KC; ns = p.x1_ns; fast = p.x1_fast; vec = p.x1_vec; }
+    else { src = p.x2; ld = p.x2_ld; csrc = p.c2; cbase = (kc - p.kc1) * KC; ns = p.x2_ns; fast = p.x2_fast; vec = p.x2_vec; }
     const T* base = reinterpret_cast<const T*>(src) + (long long)n * ns;
-    for (int idx = tid; idx < R * 8; idx += THREADS) {
-      const int i = idx >> 3, c = idx & 7;
-      const int g = rowbase + i, e0 = cbase + c * EPC;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (g >= 0 && g < p.l_in && e0 < csrc) {
-        const T* ptr = base + (long long)g * ld + e0;
-        if (vec && e0 + EPC <= csrc) {
-          v = *reinterpret_cast<const u32x4*>(ptr);
-        } else {
-          union { u32x4 u; T e[EPC]; } tmp;
-          tmp.u = u32x4{0u, 0u, 0u, 0u};
-          for (int k = 0; k < EPC; ++k)
-            if (e0 + k < csrc) tmp.e[k] = ptr[k];
-          v = tmp.u;
-        }
+    char* dst = xbuf + buf * p.xbytes;
+    if (fast) {
+      const int pieces = (R + 7) >> 3;
+      const int rl = lane >> 3, cp = lane & 7;
+      for (int pc = wave; pc < pieces; pc += THREADS / 64) {
+        const int i = pc * 8 + rl;
+        const int c = swz(i, cp);
+        const int g = i < rows0 ? g0a + p.stride * i : g0b + p.stride * (i - rows0);
+        const int e0 = cbase + c * EPC;
+        const bool ok = i < R && g >= 0 && g < p.l_in && e0 < csrc;
+        const char* sp = ok ? reinterpret_cast<const char*>(base + (long long)g * ld + e0)
+                            : reinterpret_cast<const char*>(&g_zero_chunk);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                         (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
       }
-      *reinterpret_cast<u32x4*>(xbuf + i * 128 + (swz(i, c) << 4)) = v;
+    } else {
+      for (int idx = tid; idx < R * 8; idx += THREADS) {
+        const int i = idx >> 3, c = idx & 7;
+        const int g = i < rows0 ? g0a + p.stride * i : g0b + p.stride * (i - rows0);
+        const int e0 = cbase + c * EPC;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (g >= 0 && g < p.l_in && e0 < csrc) {
+          const T* ptr = base + (long long)g * ld + e0;
+          if (vec && e0 + EPC <= csrc) {
+            v = *reinterpret_cast<const u32x4*>(ptr);
+          } else {
+            union { u32x4 u; T e[EPC]; } tmp;
+            tmp.u = u32x4{0u, 0u, 0u, 0u};
+            for (int k = 0; k < EPC; ++k)
+              if (e0 + k < csrc) tmp.e[k] = ptr[k];
+            v = tmp.u;
+          }
+        }
+        *reinterpret_cast<u32x4*>(dst + i * 128 + (swz(i, c) << 4)) = v;
+      }
     }
   };
 
@@ -145,14 +179,15 @@ __global__ __launch_bounds__(THREADS, 2) void conv_fwd_kernel(const ConvK p) {
   for (int mi = 0; mi < 4; ++mi) a_off[mi] = (wm * 64 + mi * 16 + l15) * 128;
   const int a_sw = (l15 >> 1) & 7;  // (row>>1)&7 for rows = 16k + l15
 
-  auto compute = [&](int step, int buf) {
-    const int kc = step / nt, j = step - kc * nt;
-    (void)kc;
-    const int d = p.tap_off[tb + j] - omin;
-    const char* wb = wbuf + buf * WTILE_BYTES;
-    int b_row[NI];
+  auto compute = [&](int j, const char* wb, const char* xb) {
+    const int r0 = p.tap_row[tb + j] + wn * (BN / 2) + l15;
+    int b_off[NI], b_sw[NI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) b_row[ni] = p.stride * (wn * (BN / 2) + ni * 16 + l15) + d;
+    for (int ni = 0; ni < NI; ++ni) {
+      const int row = r0 + ni * 16;
+      b_off[ni] = row * 128;
+      b_sw[ni] = (row >> 1) & 7;
+    }
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const int chunk = F32 ? ks : ks * 4 + lq;
@@ -161,8 +196,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_fwd_kernel(const ConvK p) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) a[mi] = Mma<F32>::ld(wb + a_off[mi] + ((chunk ^ a_sw) << 4) + sub);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-        b[ni] = Mma<F32>::ld(xbuf + b_row[ni] * 128 + (swz(b_row[ni], chunk) << 4) + sub);
+      for (int ni = 0; ni < NI; ++ni) b[ni] = Mma<F32>::ld(xb + b_off[ni] + ((chunk ^ b_sw[ni]) << 4) + sub);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -170,19 +204,27 @@ __global__ __launch_bounds__(THREADS, 2) void conv_fwd_kernel(const ConvK p) {
     }
   };
 
-  // ---- main loop: steps = K-chunks x taps; W double-buffered by LDS-DMA ----------------------
+  // ---- main loop: steps = K-chunks x taps.  Weight tiles are always prefetched one step ahead by
+  // LDS-DMA; the input tile of the next K-chunk is prefetched too when two of them fit (small tap
+  // spans: 1x1, k=3, transposed conv), otherwise it is restaged between chunks (23-tap convs, where
+  // one tile feeds 23 steps and the second resident block covers the bubble). ---------------------
   const int steps = p.kctot * nt;
   if (steps > 0) {
     issue_w(0, 0);
-    stage_x(0);
+    issue_x(0, 0);
+    int kc = 0, j = 0;
     for (int s = 0; s < steps; ++s) {
-      __syncthreads();  // W(s) landed (vmcnt(0) by the compiler), X tile visible, buf[(s+1)&1] free
-      if (s + 1 < steps) issue_w(s + 1, (s + 1) & 1);
-      compute(s, s & 1);
-      if (s + 1 < steps && (s + 1) % nt == 0) {
-        __syncthreads();  // every wave is done with the X tile of this K-chunk
-        stage_x((s + 1) / nt);
+      __syncthreads();  // everything issued so far has landed (vmcnt(0)) and the previous step's reads are done
+      const bool more = s + 1 < steps;
+      const bool newchunk = more && (j + 1 == nt);
+      if (more) issue_w(s + 1, (s + 1) & 1);
+      if (newchunk && p.xdb) issue_x(kc + 1, (kc + 1) & 1);
+      compute(j, wbuf + (s & 1) * WTILE_BYTES, xbuf + (p.xdb ? (kc & 1) * p.xbytes : 0));
+      if (newchunk && !p.xdb) {
+        __syncthreads();  // every wave is done with the input tile of this K-chunk
+        issue_x(kc + 1, 0);
       }
+      if (++j == nt) { j = 0; ++kc; }
     }
   }
 
@@ -539,10 +581,46 @@ bool vec8_ok(const void* p, long long ld, long long ns, int es) {  // 4-element 
   return (reinterpret_cast<uintptr_t>(p) % b) == 0 && (ld * es) % b == 0 && (ns * es) % b == 0;
 }
 
+// per-phase LDS image geometry for a tile of `bn` output positions
+struct TileGeom { int seg_rows[2][2]; int seg_q0[2][2]; int tap_row[UNET_MAX_TAPS]; int rmax; };
+
+void tile_geom(const UnetConvDesc* d, const Phases& ph, int bn, TileGeom* tg) {
+  tg->rmax = 0;
+  for (int j = 0; j < UNET_MAX_TAPS; ++j) tg->tap_row[j] = 0;
+  for (int r = 0; r < 2; ++r) {
+    int qmin[2] = {1 << 30, 1 << 30}, qmax[2] = {-(1 << 30), -(1 << 30)};
+    for (int j = ph.pbeg[r]; j < ph.pbeg[r + 1]; ++j) {
+      const int off = d->tap_off[j];
+      const int c = d->stride == 2 ? ((off % 2) + 2) % 2 : 0;
+      const int q = d->stride == 2 ? (off - c) / 2 : off;
+      qmin[c] = q < qmin[c] ? q : qmin[c];
+      qmax[c] = q > qmax[c] ? q : qmax[c];
+    }
+    int base = 0;
+    for (int c = 0; c < 2; ++c) {
+      const bool used = qmax[c] >= qmin[c];
+      tg->seg_rows[r][c] = used ? bn + qmax[c] - qmin[c] : 0;
+      tg->seg_q0[r][c] = used ? qmin[c] : 0;
+    }
+    for (int j = ph.pbeg[r]; j < ph.pbeg[r + 1]; ++j) {
+      const int off = d->tap_off[j];
+      const int c = d->stride == 2 ? ((off % 2) + 2) % 2 : 0;
+      const int q = d->stride == 2 ? (off - c) / 2 : off;
+      tg->tap_row[j] = (c ? tg->seg_rows[r][0] : 0) + q - qmin[c];
+    }
+    (void)base;
+    const int rows = tg->seg_rows[r][0] + tg->seg_rows[r][1];
+    tg->rmax = rows > tg->rmax ? rows : tg->rmax;
+  }
+}
+
 template <bool F32, int BN>
-int launch_fwd(const ConvK& k, int rmax, hipStream_t st) {
+int launch_fwd(ConvK& k, int rmax, hipStream_t st) {
   static bool attr_set = false;
-  const size_t lds = 2 * WTILE_BYTES + (size_t)rmax * 128;
+  const int xbytes = ((rmax + 7) / 8) * 1024;
+  k.xbytes = xbytes;
+  k.xdb = (2 * WTILE_BYTES + 2 * (size_t)xbytes <= 80 * 1024) ? 1 : 0;
+  const size_t lds = 2 * WTILE_BYTES + (size_t)xbytes * (k.xdb ? 2 : 1);
   UNET_REQUIRE(lds <= 160 * 1024, "conv: tap span needs %zu bytes of LDS (max 163840)", lds);
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_kernel<F32, BN>),
@@ -607,32 +685,32 @@ extern "C" int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void
   k.stride = d->stride; k.up = d->up; k.act = d->act;
   k.mtiles = cdiv(d->c_out, BM);
   for (int r = 0; r < 3; ++r) k.pbeg[r] = ph.pbeg[r];
-  for (int j = 0; j < UNET_MAX_TAPS; ++j) k.tap_off[j] = j < d->n_taps ? d->tap_off[j] : 0;
   k.x1_vec = vec_ok(x1, d->x1_ld, d->x1_ns, es);
   k.x2_vec = x2 ? vec_ok(x2, d->x2_ld, d->x2_ns, es) : 0;
+  const int epc = d->dtype == UNET_F32 ? 4 : 8;
+  k.x1_fast = k.x1_vec && d->c1 % epc == 0;
+  k.x2_fast = k.x2_vec && d->c2 % epc == 0;
   k.y_vec = vec8_ok(y, d->y_ld, d->y_ns, es);
   k.res_vec = res ? vec8_ok(res, d->res_ld, d->res_ns, es) : 0;
+  for (int r = 0; r < 2; ++r) k.mcount[r] = ph.mcount[r];
   // tile width: 128 positions unless the halo tile would not leave room for two blocks per CU
-  int span = 0;
-  for (int r = 0; r < 2; ++r) {
-    k.omin[r] = ph.omin[r]; k.omax[r] = ph.omax[r]; k.mcount[r] = ph.mcount[r];
-    int s = ph.omax[r] - ph.omin[r] + 1;
-    span = s > span ? s : span;
-  }
+  TileGeom tg;
   int bn = 128;
+  tile_geom(d, ph, 128, &tg);
   {
     const char* env = getenv("UNET_CONV_BN");
     if (env && atoi(env) == 64) bn = 64;
-    else if (!env) {
-      const size_t lds128 = 2 * WTILE_BYTES + (size_t)(d->stride * 127 + span) * 128;
-      if (lds128 > 80 * 1024) bn = 64;
-    }
+    else if (!env && 2 * WTILE_BYTES + (size_t)((tg.rmax + 7) / 8) * 1024 > 80 * 1024) bn = 64;
   }
-  for (int r = 0; r < 2; ++r) k.ptiles[r] = (r < d->up) ? cdiv(ph.mcount[r], bn) : 0;
-  const int rmax = d->stride * (bn - 1) + span;
+  if (bn != 128) tile_geom(d, ph, bn, &tg);
+  for (int r = 0; r < 2; ++r) {
+    k.ptiles[r] = (r < d->up) ? cdiv(ph.mcount[r], bn) : 0;
+    for (int c = 0; c < 2; ++c) { k.seg_rows[r][c] = tg.seg_rows[r][c]; k.seg_q0[r][c] = tg.seg_q0[r][c]; }
+  }
+  for (int j = 0; j < UNET_MAX_TAPS; ++j) k.tap_row[j] = tg.tap_row[j];
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (d->dtype == UNET_F32) return bn == 128 ? launch_fwd<true, 128>(k, rmax, st) : launch_fwd<true, 64>(k, rmax, st);
-  return bn == 128 ? launch_fwd<false, 128>(k, rmax, st) : launch_fwd<false, 64>(k, rmax, st);
+  if (d->dtype == UNET_F32) return bn == 128 ? launch_fwd<true, 128>(k, tg.rmax, st) : launch_fwd<true, 64>(k, tg.rmax, st);
+  return bn == 128 ? launch_fwd<false, 128>(k, tg.rmax, st) : launch_fwd<false, 64>(k, tg.rmax, st);
 }
 
 namespace {
