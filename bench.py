@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=2)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch kernels one by one (hook-driven overlapped "
+                    "all-reduce) instead of replaying the captured HIP graph")
     return ap.parse_args()
 
 
@@ -100,9 +102,8 @@ def main():
     broadcast_parameters(model)
     n_params = sum(p.numel() for p in model.parameters())
 
-    reducer = BucketedGradAllReduce(model.parameters())
     opt = torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.7595905764360957, 0.920298282605139),
-                            weight_decay=0.0, fused=True)  # train.py:183-193
+                            weight_decay=0.0, fused=True, capturable=not args.eager)  # train.py:183-193
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B = args.batch
@@ -111,10 +112,31 @@ def main():
     tgt = (tgt - tgt.mean(-1, keepdim=True)) / tgt.std(-1, keepdim=True).clamp(min=1e-6)  # train.py:476-495
     ids = torch.zeros(B, dtype=torch.long, device=dev)
 
+    def loss_fn(pred, target):
+        return F.l1_loss(pred[..., CROP[0]:CROP[1]].float(), target[..., CROP[0]:CROP[1]])  # train.py:1481-1486
+
+    mode = "eager"
+    graphed = None
+    if not args.eager:
+        try:
+            from unet_amd.graphs import GraphedTrainStep
+            graphed = GraphedTrainStep(model, loss_fn, opt, [ob, ids], [tgt], clip_norm=5.0)
+            mode = "hipgraph"
+        except Exception as e:  # capture unsupported in this environment: run the same step eagerly
+            import traceback
+            traceback.print_exc()
+            print(f"[bench] HIP-graph capture failed ({type(e).__name__}); running eagerly", file=sys.stderr)
+            graphed = None
+            opt = torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.7595905764360957, 0.920298282605139),
+                                    weight_decay=0.0, fused=True)
+    if graphed is None:
+        reducer = BucketedGradAllReduce(model.parameters())
+
     def step():
+        if graphed is not None:
+            return graphed()
         reducer.zero_grad()
-        pred = model(ob, ids)
-        loss = F.l1_loss(pred[..., CROP[0]:CROP[1]].float(), tgt[..., CROP[0]:CROP[1]])
+        loss = loss_fn(model(ob, ids), tgt)
         loss.backward()
         reducer.finish()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)  # train.py:1553 GRAD_CLIP
@@ -129,7 +151,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    if not args.no_kernel_timing:
+    if not args.no_kernel_timing and graphed is None:
         ops.PROFILE = []
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
@@ -137,6 +159,7 @@ def main():
     for i in range(args.steps):
         loss = step()
         evs[i + 1].record()
+    host_dt = time.perf_counter() - t0   # time to ENQUEUE the steps (host side); < dt when the GPU is the bottleneck
     sync()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
@@ -155,8 +178,8 @@ def main():
         "config": {"workload": "config B: CondUNet1D train.py/LOSO default (base=256, modern 4x dilated k7 + SE, FiLM, "
                                "skip add, BN), 32ch x 4096 windows, 64 windows/GPU, fwd + L1[500:4500] + bwd + "
                                "grad all-reduce + clip 5.0 + AdamW", "windows_per_gpu": B, "params": n_params,
-                   "parallelism": f"dp{world}"},
-        "final_loss": float(loss.item()),
+                   "parallelism": f"dp{world}", "launch": mode},
+        "final_loss": float(loss.item()), "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
         "ms_each_step": [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(args.steps)],
         "model_tflops_algorithmic": value * 3 * GFLOP_PER_WINDOW_FWD / 1e3,
         "frac_of_bf16_mfma_peak_end_to_end": value * 3 * GFLOP_PER_WINDOW_FWD / 1e3 / (BF16_DENSE_PEAK_TFLOPS * world),

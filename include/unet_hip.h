@@ -118,6 +118,22 @@ int unet_nlc_to_ncl(int32_t dtype, int32_t out_dtype, const void* x, const void*
 int unet_rowstats(int32_t dtype, const void* y, float* s1_part, float* s2_part, int32_t n,
                   int32_t rows, int32_t c, void* stream);
 
+/* BatchNorm1d training-mode statistics (models.py:540, 804; torch defaults eps 1e-5, momentum 0.1):
+ * from the unet_rowstats partials compute, per channel, mean / biased var / rstd, update the running
+ * buffers in place (unbiased var; may be NULL), and emit mean/rstd/a/b as [n][c] fp32 with
+ * a = gamma*rstd, b = beta - mean*a  (gamma/beta NULL = 1/0). */
+int unet_bn_finalize_fwd(const float* s1_part, const float* s2_part, int32_t n, int32_t parts, int32_t c,
+                         int32_t rows, float eps, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float* mean,
+                         float* rstd, float* a, float* b, void* stream);
+/* ... and its backward: from the unet_affine_act_bwd_reduce partials compute dgamma/dbeta [c] and the
+ * coefficients ca/cb/cc [n][c] of unet_affine_act_bwd_apply. */
+int unet_bn_finalize_bwd(const float* g1_part, const float* g2_part, int32_t n, int32_t parts, int32_t c,
+                         int32_t rows, const float* mean, const float* rstd, const float* gamma, float* ca,
+                         float* cb, float* cc, float* dgamma, float* dbeta, void* stream);
+/* out[c] = sum_r in[r][c]  (fp64 accumulation; second stage of the column-sum partials) */
+int unet_reduce_rows(const float* in, int32_t rows, int32_t c, float* out, void* stream);
+
 /* z = act(a[n][c]*y + b[n][c]); pool_part = partial sum_t z  (norm-apply + GELU + SE squeeze,
  * models.py:559-560, 827, 649/660).  pool_part may be NULL. */
 int unet_affine_act_fwd(int32_t dtype, const void* y, const float* a, const float* b, int32_t act,

@@ -424,6 +424,89 @@ __global__ __launch_bounds__(THREADS) void film_softmax_bwd_kernel(const T* q, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// BatchNorm (training) statistics finalisation: one launch replaces ~30 tiny tensor ops.
+// block = 64 channels x 4 segments of the (window, part) range; fp64 accumulation.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* s1p, const float* s2p, int n, int parts, int c,
+                                                              double count, float eps, const float* gamma,
+                                                              const float* beta, float* run_mean, float* run_var,
+                                                              float momentum, float* mean_o, float* rstd_o, float* a_o,
+                                                              float* b_o) {
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int ch = blockIdx.x * 64 + cl;
+  const int total = n * parts;
+  double a1 = 0.0, a2 = 0.0;
+  if (ch < c)
+    for (int i = seg; i < total; i += 4) { a1 += s1p[(long long)i * c + ch]; a2 += s2p[(long long)i * c + ch]; }
+  red[0][seg][cl] = a1; red[1][seg][cl] = a2;
+  __syncthreads();
+  if (ch >= c) return;
+  const double s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+  const double s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  if (seg == 0 && run_mean) {
+    const double unb = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
+    run_mean[ch] = (float)((1.0 - momentum) * run_mean[ch] + momentum * mean);
+    run_var[ch] = (float)((1.0 - momentum) * run_var[ch] + momentum * unb);
+  }
+  const double g = gamma ? (double)gamma[ch] : 1.0, bt = beta ? (double)beta[ch] : 0.0;
+  const float a = (float)(rstd * g), b = (float)(bt - mean * rstd * g);
+  for (int i = seg; i < n; i += 4) {
+    const long long o = (long long)i * c + ch;
+    mean_o[o] = (float)mean; rstd_o[o] = (float)rstd; a_o[o] = a; b_o[o] = b;
+  }
+}
+
+// backward: dgamma, dbeta and the per-(window, channel) coefficients of  dy = ca*g + cb*y + cc
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* g1p, const float* g2p, int n, int parts, int c,
+                                                              double count, const float* mean_i, const float* rstd_i,
+                                                              const float* gamma, float* ca_o, float* cb_o, float* cc_o,
+                                                              float* dgamma, float* dbeta) {
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int ch = blockIdx.x * 64 + cl;
+  const int total = n * parts;
+  double a1 = 0.0, a2 = 0.0;
+  if (ch < c)
+    for (int i = seg; i < total; i += 4) { a1 += g1p[(long long)i * c + ch]; a2 += g2p[(long long)i * c + ch]; }
+  red[0][seg][cl] = a1; red[1][seg][cl] = a2;
+  __syncthreads();
+  if (ch >= c) return;
+  const double g1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+  const double g2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+  const double mean = mean_i[ch], rstd = rstd_i[ch];   // row 0 of the [n][c] arrays (identical for all windows)
+  const double gm = gamma ? (double)gamma[ch] : 1.0;
+  const double gy = rstd * (g2 - mean * g1);           // sum g * yhat
+  if (seg == 0) {
+    if (dgamma) dgamma[ch] = (float)gy;
+    if (dbeta) dbeta[ch] = (float)g1;
+  }
+  const double m1 = gm * g1 / count, m2 = gm * gy / count;
+  const float ca = (float)(rstd * gm), cb = (float)(-rstd * rstd * m2), cc = (float)(-rstd * m1 + rstd * rstd * mean * m2);
+  for (int i = seg; i < n; i += 4) {
+    const long long o = (long long)i * c + ch;
+    ca_o[o] = ca; cb_o[o] = cb; cc_o[o] = cc;
+  }
+}
+
+// out[c] = sum over rows of in[rows][c]   (second stage of the per-part column sums)
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* in, int rows, int c, float* out) {
+  __shared__ double red[4][64];
+  const int cl = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int ch = blockIdx.x * 64 + cl;
+  double a = 0.0;
+  if (ch < c)
+    for (int i = seg; i < rows; i += 4) a += in[(long long)i * c + ch];
+  red[seg][cl] = a;
+  __syncthreads();
+  if (ch < c && seg == 0) out[ch] = (float)(red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
 template <typename T, int V>
 int film_dispatch(bool bwd, const void* q, const void* dh, const float* kk, const float* v, void* out,
                   float* dkk, float* dv, int n, int rows, int c, hipStream_t st) {
@@ -735,4 +818,36 @@ extern "C" int unet_nlc_to_ncl(int32_t dtype, int32_t out_dtype, const void* x, 
   if (dtype == UNET_BF16) return transpose_out<__bf16>(out_dtype, x, x2, y, ga, gb, be, n, c, t, st);
   unet_set_error("nlc_to_ncl: bad dtype %d", dtype);
   return -1;
+}
+
+extern "C" int unet_bn_finalize_fwd(const float* s1_part, const float* s2_part, int32_t n, int32_t parts, int32_t c,
+                                    int32_t rows, float eps, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float* mean,
+                                    float* rstd, float* a, float* b, void* stream) {
+  UNET_REQUIRE(s1_part && s2_part && mean && rstd && a && b && n > 0 && parts > 0 && c > 0 && rows > 0,
+               "bn_finalize_fwd: bad arguments");
+  UNET_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_fwd: running stats must come in pairs");
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(256), 0, static_cast<hipStream_t>(stream), s1_part,
+                     s2_part, n, parts, c, (double)n * rows, eps, gamma, beta, running_mean, running_var, momentum, mean,
+                     rstd, a, b);
+  UNET_LAUNCH_CHECK("bn_finalize_fwd");
+  return 0;
+}
+
+extern "C" int unet_bn_finalize_bwd(const float* g1_part, const float* g2_part, int32_t n, int32_t parts, int32_t c,
+                                    int32_t rows, const float* mean, const float* rstd, const float* gamma, float* ca,
+                                    float* cb, float* cc, float* dgamma, float* dbeta, void* stream) {
+  UNET_REQUIRE(g1_part && g2_part && mean && rstd && ca && cb && cc && n > 0 && parts > 0 && c > 0 && rows > 0,
+               "bn_finalize_bwd: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(256), 0, static_cast<hipStream_t>(stream), g1_part,
+                     g2_part, n, parts, c, (double)n * rows, mean, rstd, gamma, ca, cb, cc, dgamma, dbeta);
+  UNET_LAUNCH_CHECK("bn_finalize_bwd");
+  return 0;
+}
+
+extern "C" int unet_reduce_rows(const float* in, int32_t rows, int32_t c, float* out, void* stream) {
+  UNET_REQUIRE(in && out && rows > 0 && c > 0, "reduce_rows: bad arguments");
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(c, 64)), dim3(256), 0, static_cast<hipStream_t>(stream), in, rows, c, out);
+  UNET_LAUNCH_CHECK("reduce_rows");
+  return 0;
 }

@@ -5,15 +5,19 @@ and its per-tensor ``sync_gradients_manual`` (train.py:738-758) for one-process-
 RCCL/xGMI (backend "nccl" on ROCm) -- and over gloo on CPU for the tests.
 
 Design (MI355X-first, not DDP's reducer re-typed):
-  * every parameter's ``.grad`` is a VIEW into one of a few flat fp32 bucket buffers, so autograd
-    accumulates straight into communication memory: no gather copy before, no scatter copy after;
-  * buckets are filled in reverse parameter-registration order (the order backward produces
-    gradients); when the last gradient of a bucket has been accumulated its all-reduce is issued
-    asynchronously, so RCCL moves bucket k over xGMI while the HIP kernels compute bucket k+1;
+  * gradients are exchanged in a few flat fp32 buckets filled in reverse parameter-registration
+    order (the order backward produces them).  When the last gradient of a bucket has been produced
+    (post-accumulate hook) the bucket is packed with ONE multi-tensor copy, every ``.grad`` is
+    re-pointed at its slice of the flat buffer (so the optimizer reads communication memory directly,
+    no scatter copy after the reduce), and the all-reduce is issued asynchronously: RCCL moves
+    bucket k over xGMI while the HIP kernels compute the gradients of bucket k+1;
+  * ``zero_grad()`` only drops the ``.grad`` references (set-to-none): autograd then *assigns* fresh
+    gradients instead of launching one tiny accumulate kernel per parameter (145 of them at config B);
   * BatchNorm buffers are never synchronised (per-rank statistics, as in the reference:
-    ``broadcast_buffers=False``); rank 0's buffers are what a checkpoint holds.
+    ``broadcast_buffers=False``); rank 0's buffers are what a checkpoint holds;
   * xGMI is point-to-point (7 links per GPU), so fewer, larger buckets are preferred: default
-    64 MiB (the 168 MB of config-B gradients travel as 3 messages).
+    64 MiB (the 168 MB of config-B gradients travel as 3 messages);
+  * with one process there is nothing to exchange and the class is a no-op around autograd.
 """
 from __future__ import annotations
 
@@ -30,44 +34,44 @@ class BucketedGradAllReduce:
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets: List[torch.Tensor] = []
+        self._groups: List[List[torch.nn.Parameter]] = []
+        self._views: List[List[torch.Tensor]] = []
         self._bucket_of = {}
-        self._pending: List[int] = []
-        self._expected: List[int] = []
         self._handles = []
         self._hooks = []
-        order = list(reversed(self.params))
         cur, cur_elems = [], 0
-        groups = []
-        for p in order:
+        for p in reversed(self.params):
             if p.dtype != torch.float32:
                 raise TypeError("gradient buckets are fp32 (master weights are fp32, as in the reference)")
             if cur and (cur_elems + p.numel()) * 4 > bucket_bytes:
-                groups.append(cur)
+                self._groups.append(cur)
                 cur, cur_elems = [], 0
             cur.append(p)
             cur_elems += p.numel()
         if cur:
-            groups.append(cur)
-        for b, group in enumerate(groups):
-            total = sum(p.numel() for p in group)
-            flat = torch.zeros(total, dtype=torch.float32, device=group[0].device)
-            off = 0
+            self._groups.append(cur)
+        for b, group in enumerate(self._groups):
+            flat = torch.zeros(sum(p.numel() for p in group), dtype=torch.float32, device=group[0].device)
+            views, off = [], 0
             for p in group:
-                p.grad = flat[off:off + p.numel()].view_as(p)
+                views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
                 self._bucket_of[p] = b
             self.buckets.append(flat)
-            self._expected.append(len(group))
+            self._views.append(views)
+        self._expected = [len(g) for g in self._groups]
         self._pending = list(self._expected)
-        for p in self.params:
-            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._launched = [False] * len(self._groups)
+        if self.world > 1:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     # -- per-step protocol --------------------------------------------------------------------
     def zero_grad(self):
-        """Zero the flat buffers in place (keeps .grad views alive -- never set_to_none)."""
-        for flat in self.buckets:
-            flat.zero_()
+        for p in self.params:
+            p.grad = None
         self._pending = list(self._expected)
+        self._launched = [False] * len(self._groups)
         self._handles = []
 
     def _on_grad(self, p: torch.nn.Parameter):
@@ -77,23 +81,30 @@ class BucketedGradAllReduce:
             self._launch(b)
 
     def _launch(self, b: int):
-        if self.world == 1:
+        if self.world == 1 or self._launched[b]:
             return
-        flat = self.buckets[b]
+        self._launched[b] = True
+        flat, group, views = self.buckets[b], self._groups[b], self._views[b]
+        have = [(v, p.grad) for v, p in zip(views, group) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        with torch.no_grad():
+            if have:
+                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+            for v, p in zip(views, group):
+                if p.grad is None:
+                    v.zero_()  # parameter unused this step: contributes zeros (find_unused_parameters semantics)
+                p.grad = v
         if self.average and flat.is_cuda:
             h = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
             self._handles.append((h, None))
-        else:
+        else:  # gloo has no AVG
             h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             self._handles.append((h, flat if self.average else None))
 
     def finish(self):
-        """Call after backward: launches buckets whose parameters received no gradient this step
-        (find_unused_parameters semantics: they contribute zeros), then waits for every bucket."""
-        for b, left in enumerate(self._pending):
-            if left > 0:
-                self._pending[b] = 0
-                self._launch(b)
+        """Call after backward: flushes buckets that did not fill (some parameter got no gradient this
+        step), then waits for every bucket."""
+        for b in range(len(self._groups)):
+            self._launch(b)
         for h, scale in self._handles:
             h.wait()
             if scale is not None:

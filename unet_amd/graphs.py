@@ -1,0 +1,141 @@
+"""HIP-graph capture of the training step.
+
+One config-B training step launches ~1000 kernels; issued one by one from Python the host needs
+longer to enqueue them than the MI355X needs to run them.  Windows have a fixed shape, so the whole
+step is captured once into a HIP graph (``torch.cuda.CUDAGraph`` = ``hipGraph`` on ROCm) and replayed
+with one launch per step.  The HIP kernels of libunet_hip.so are capture-safe by construction: they
+never allocate, never synchronise, and launch only on the stream they are given (torch's current
+stream, which is the capture stream during capture).
+
+Single process:   [ zero-grad | forward | loss | backward | clip | optimizer ]      = one graph
+Data parallel:    [ forward | loss | backward ] graph  ->  bucket pack + RCCL all-reduce (eager,
+                  outside any graph)  ->  [ clip | optimizer ] graph
+(The eager path -- ``BucketedGradAllReduce`` hooks -- overlaps the all-reduce with backward instead;
+``GraphedTrainStep`` trades that overlap for zero launch overhead.)
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+class GraphedTrainStep:
+    """Capture ``loss = loss_fn(model(*inputs), *targets); loss.backward(); clip; optimizer.step()``.
+
+    ``inputs`` / ``targets`` given at construction define the static shapes; ``__call__`` copies new
+    batches into the static buffers and replays.  Returns the (static) loss tensor.
+    """
+
+    def __init__(self, model: torch.nn.Module, loss_fn: Callable, optimizer: torch.optim.Optimizer,
+                 inputs: Sequence[torch.Tensor], targets: Sequence[torch.Tensor], clip_norm: Optional[float] = None,
+                 warmup: int = 3, process_group=None, bucket_bytes: int = 64 << 20):
+        self.model, self.loss_fn, self.opt, self.clip = model, loss_fn, optimizer, clip_norm
+        self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
+        self.static_in = [t.clone() for t in inputs]
+        self.static_tg = [t.clone() for t in targets]
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+
+        def fwd_bwd():
+            out = model(*self.static_in)
+            loss = loss_fn(out, *self.static_tg)
+            loss.backward()
+            return loss
+
+        def update():
+            if self.clip is not None:
+                torch.nn.utils.clip_grad_norm_(self.params, self.clip)
+            self.opt.step()
+
+        # warm-up on a side stream (allocator pools, lazy kernel attributes, optimizer state)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                self.opt.zero_grad(set_to_none=True)
+                fwd_bwd()
+                if self.world > 1:
+                    self._reduce_eager_setup(bucket_bytes)
+                    self._allreduce()
+                update()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+        self.opt.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        if self.world == 1:
+            with torch.cuda.graph(self.graph):
+                self.loss = fwd_bwd()
+                update()
+            self.graph_update = None
+        else:
+            with torch.cuda.graph(self.graph):
+                self.loss = fwd_bwd()
+            self.static_grads = [p.grad for p in self.params]
+            for p, v in zip(self.params, self._views):
+                p.grad = v                                   # the optimizer reads the reduced buckets
+            self.graph_update = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_update):
+                update()
+
+    # -- data-parallel pieces (eager, outside the graphs) ---------------------------------------
+    def _reduce_eager_setup(self, bucket_bytes: int):
+        if hasattr(self, "_flat"):
+            return
+        self._flat, self._views = [], []
+        cur, cur_elems, groups = [], 0, []
+        for p in reversed(self.params):
+            if cur and (cur_elems + p.numel()) * 4 > bucket_bytes:
+                groups.append(cur)
+                cur, cur_elems = [], 0
+            cur.append(p)
+            cur_elems += p.numel()
+        if cur:
+            groups.append(cur)
+        view_of = {}
+        for grp in groups:
+            flat = torch.zeros(sum(p.numel() for p in grp), dtype=torch.float32, device=grp[0].device)
+            off = 0
+            for p in grp:
+                view_of[p] = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            self._flat.append(flat)
+        self._views = [view_of[p] for p in self.params]
+
+    def _allreduce(self, grads: Optional[List[torch.Tensor]] = None):
+        grads = grads if grads is not None else [p.grad for p in self.params]
+        src = [(v, g) for v, g in zip(self._views, grads) if g is not None]
+        with torch.no_grad():
+            torch._foreach_copy_([v for v, _ in src], [g for _, g in src])
+            for v, g in zip(self._views, grads):
+                if g is None:
+                    v.zero_()
+        handles = []
+        for flat in self._flat:
+            if flat.is_cuda:
+                handles.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))
+            else:
+                handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), flat))
+        for h, scale in handles:
+            h.wait()
+            if scale is not None:
+                scale.div_(self.world)
+        if grads is not self.__dict__.get("static_grads"):
+            for p, v in zip(self.params, self._views):
+                p.grad = v
+
+    # -- per step ---------------------------------------------------------------------------------
+    def __call__(self, inputs: Optional[Sequence[torch.Tensor]] = None, targets: Optional[Sequence[torch.Tensor]] = None):
+        if inputs is not None:
+            for s, t in zip(self.static_in, inputs):
+                s.copy_(t, non_blocking=True)
+        if targets is not None:
+            for s, t in zip(self.static_tg, targets):
+                s.copy_(t, non_blocking=True)
+        self.graph.replay()
+        if self.graph_update is not None:
+            self._allreduce(self.static_grads)
+            self.graph_update.replay()
+        return self.loss

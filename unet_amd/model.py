@@ -84,22 +84,19 @@ def _norm_act(y: Tensor, norm: nn.Module, act_id: int, want_pool: bool):
     if isinstance(norm, nn.BatchNorm1d):
         use_batch = norm.training or norm.running_mean is None
         if use_batch:
-            s1, s2 = ops.rowstats(y)
-            cnt = n * rows
-            mean_c = s1.sum(0) / cnt
-            var_c = (s2.sum(0) / cnt - mean_c * mean_c).clamp_min(0.0)
-            if norm.training and norm.track_running_stats and norm.running_mean is not None:
+            track = norm.training and norm.track_running_stats and norm.running_mean is not None
+            mom = norm.momentum
+            if track:
                 with torch.no_grad():
                     norm.num_batches_tracked += 1
-                    mom = norm.momentum
-                    if mom is None:
-                        mom = 1.0 / float(norm.num_batches_tracked)
-                    unbiased = var_c * (cnt / max(cnt - 1, 1))
-                    norm.running_mean.mul_(1 - mom).add_(mean_c.to(norm.running_mean.dtype), alpha=mom)
-                    norm.running_var.mul_(1 - mom).add_(unbiased.to(norm.running_var.dtype), alpha=mom)
-            rstd_c = torch.rsqrt(var_c + norm.eps)
-            stats = dict(mean=mean_c[None, :].expand(n, c), rstd=rstd_c[None, :].expand(n, c), coupled=True,
-                         count=float(cnt), reduce=lambda v: v.sum(0, keepdim=True))
+                if mom is None:  # cumulative moving average (not used by the reference; needs a host read)
+                    mom = 1.0 / float(norm.num_batches_tracked)
+            rm = norm.running_mean if track else None
+            rv = norm.running_var if track else None
+            if rm is not None and (rm.dtype != torch.float32 or not rm.is_contiguous()):
+                raise TypeError("BatchNorm running buffers must be contiguous fp32")
+            return ops.BatchNormActFn.apply(y, norm.weight, norm.bias, rm, rv, float(mom or 0.0), float(norm.eps),
+                                            act_id, want_pool)
         else:
             mean_c = norm.running_mean.double()
             rstd_c = torch.rsqrt(norm.running_var.double() + norm.eps)
@@ -344,7 +341,8 @@ class _UpMixin:
 
     def _up_forward(self, x: Tensor, skip: Tensor, emb: Optional[Tensor]) -> Tensor:
         geom, kidx = ops.geom_convt_k4s2p1()
-        w = self.up.weight.permute(2, 1, 0)[list(kidx)]          # [4 taps, Cout, Cin]
+        wk = self.up.weight.permute(2, 1, 0)                      # [k, Cout, Cin] view
+        w = torch.stack([wk[k] for k in kidx])                    # tap order (no index tensor: graph-capture safe)
         l_up = 2 * x.shape[1]
         l_skip = skip.shape[1]
         if self.skip_type == "add" and self.skip_proj is not None:

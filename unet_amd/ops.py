@@ -302,12 +302,27 @@ def _part_buf(x: Tensor, k: int = 1):
 
 
 def colsum(x: Tensor) -> Tensor:
-    """sum over windows and rows -> [C] fp32"""
+    """sum over windows and rows -> [C] fp32 (two HIP stages, fp64 accumulation in the second)"""
     lib = _lib.load()
     x = x.contiguous()
     (buf,) = _part_buf(x)
-    check(lib.unet_colsum(_dt(x), _p(x), _p(buf), *_dims(x), _stream()), "unet_colsum")
-    return buf.sum(dim=(0, 1))
+    n, rows, c = x.shape
+    check(lib.unet_colsum(_dt(x), _p(x), _p(buf), n, rows, c, _stream()), "unet_colsum")
+    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    check(lib.unet_reduce_rows(_p(buf), buf.shape[0] * buf.shape[1], c, _p(out), _stream()), "unet_reduce_rows")
+    return out
+
+
+_CONST_CACHE = {}
+
+
+def _const_nc(n: int, c: int, device, value: float) -> Tensor:
+    key = (n, c, str(device), value)
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        t = torch.full((n, c), value, dtype=torch.float32, device=device)
+        _CONST_CACHE[key] = t
+    return t
 
 
 def rowstats(y: Tensor) -> Tuple[Tensor, Tensor]:
@@ -336,8 +351,8 @@ class AffineActFn(torch.autograd.Function):
         n, rows, c = y.shape
         dev = y.device
         if stats is None:
-            a = torch.ones((n, c), dtype=torch.float32, device=dev)
-            b = torch.zeros((n, c), dtype=torch.float32, device=dev)
+            a = _const_nc(n, c, dev, 1.0)
+            b = _const_nc(n, c, dev, 0.0)
         else:
             g = gamma.detach().double() if gamma is not None else torch.ones(c, dtype=torch.float64, device=dev)
             bt = beta.detach().double() if beta is not None else torch.zeros(c, dtype=torch.float64, device=dev)
@@ -378,7 +393,7 @@ class AffineActFn(torch.autograd.Function):
             g1 = g1p.double().sum(dim=1)
             g2 = g2p.double().sum(dim=1)
         if stats is None:
-            ca, cb, cc = a, torch.zeros_like(a), torch.zeros_like(a)
+            ca, cb, cc = a, b, b  # a = 1, b = 0 constants
         else:
             mean, rstd = stats["mean"], stats["rstd"]
             gm = gamma.detach().double() if gamma is not None else torch.ones(c, dtype=torch.float64, device=y.device)
@@ -404,6 +419,64 @@ class AffineActFn(torch.autograd.Function):
                                                 _p(cb), _p(cc), _p(dy), n, rows, c, _stream()),
                   "unet_affine_act_bwd_apply")
         return dy, dgamma, dbeta, None, None, None
+
+
+class BatchNormActFn(torch.autograd.Function):
+    """z = act(BatchNorm1d_train(y)) (+ pooled sum of z): statistics, running-buffer update and the
+    affine coefficients come from ONE finalisation kernel (unet_bn_finalize_fwd); backward likewise."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum: float, eps: float, act_id: int,
+                want_pool: bool):
+        lib = _lib.load()
+        _need_cuda(y)
+        y = y.contiguous()
+        n, rows, c = y.shape
+        dt, st = _dt(y), _stream()
+        s1p, s2p = _part_buf(y, 2)
+        check(lib.unet_rowstats(dt, _p(y), _p(s1p), _p(s2p), n, rows, c, st), "unet_rowstats")
+        coef = torch.empty((4, n, c), dtype=torch.float32, device=y.device)
+        mean, rstd, a, b = coef[0], coef[1], coef[2], coef[3]
+        gf = _f32c(gamma) if gamma is not None else None
+        bf = _f32c(beta) if beta is not None else None
+        check(lib.unet_bn_finalize_fwd(_p(s1p), _p(s2p), n, s1p.shape[1], c, rows, eps, _p(gf), _p(bf),
+                                       _p(running_mean), _p(running_var), momentum, _p(mean), _p(rstd), _p(a), _p(b),
+                                       st), "unet_bn_finalize_fwd")
+        z = torch.empty_like(y)
+        pbuf = s1p if want_pool else None  # partial buffer no longer needed: reuse
+        check(lib.unet_affine_act_fwd(dt, _p(y), _p(a), _p(b), act_id, _p(z), _p(pbuf), n, rows, c, st),
+              "unet_affine_act_fwd")
+        ctx.act_id, ctx.want_pool = act_id, want_pool
+        ctx.has_affine = gamma is not None
+        ctx.gdtype = gamma.dtype if gamma is not None else torch.float32
+        ctx.save_for_backward(y, coef, gf)
+        if want_pool:
+            return z, pbuf.sum(dim=1)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz, dpool=None):
+        lib = _lib.load()
+        y, coef, gf = ctx.saved_tensors
+        mean, rstd, a, b = coef[0], coef[1], coef[2], coef[3]
+        n, rows, c = y.shape
+        dt, st = _dt(y), _stream()
+        dz = dz.contiguous()
+        dp = _f32c(dpool) if (ctx.want_pool and dpool is not None) else None
+        g1p, g2p = _part_buf(y, 2)
+        check(lib.unet_affine_act_bwd_reduce(dt, _p(y), _p(dz), _p(dp), _p(a), _p(b), ctx.act_id, _p(g1p), _p(g2p),
+                                             n, rows, c, st), "unet_affine_act_bwd_reduce")
+        cf = torch.empty((3, n, c), dtype=torch.float32, device=y.device)
+        dgb = torch.empty((2, c), dtype=torch.float32, device=y.device)
+        check(lib.unet_bn_finalize_bwd(_p(g1p), _p(g2p), n, g1p.shape[1], c, rows, _p(mean), _p(rstd), _p(gf),
+                                       _p(cf[0]), _p(cf[1]), _p(cf[2]), _p(dgb[0]), _p(dgb[1]), st),
+              "unet_bn_finalize_bwd")
+        dy = torch.empty_like(y)
+        check(lib.unet_affine_act_bwd_apply(dt, _p(y), _p(dz), _p(dp), _p(a), _p(b), ctx.act_id, _p(cf[0]), _p(cf[1]),
+                                            _p(cf[2]), _p(dy), n, rows, c, st), "unet_affine_act_bwd_apply")
+        dgamma = dgb[0].to(ctx.gdtype) if ctx.has_affine else None
+        dbeta = dgb[1].to(ctx.gdtype) if ctx.has_affine else None
+        return dy, dgamma, dbeta, None, None, None, None, None, None
 
 
 def activation(x: Tensor, act_id: int) -> Tensor:
