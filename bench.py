@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="windows per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-windows", type=int, default=2)
+    ap.add_argument("--cpu-windows", type=int, default=16, help="windows per CPU-baseline step (2 steps are timed)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one (hook-driven overlapped "
                     "all-reduce) instead of replaying the captured HIP graph")
@@ -68,12 +68,15 @@ def cpu_baseline(n_windows: int):
     ob = torch.randn(n_windows, 32, T, generator=g)
     tgt = torch.randn(n_windows, 32, T, generator=g)
     ids = torch.zeros(n_windows, dtype=torch.long)
+    reps = 2
     t0 = time.perf_counter()
-    loss = O.train_step_loss(run_sd, CONFIG_B, ob, tgt, odor_ids=ids)
-    loss.backward()
+    for _ in range(reps):
+        loss = O.train_step_loss(run_sd, CONFIG_B, ob, tgt, odor_ids=ids)
+        loss.backward()
     dt = time.perf_counter() - t0
-    return {"value": n_windows / dt, "unit": "windows/s", "cores": threads, "kind": "port",
-            "sample": f"1 fwd+bwd step of config B on {n_windows} windows (32ch x {T}), fp32, {dt:.1f} s"}
+    return {"value": reps * n_windows / dt, "unit": "windows/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} fwd+bwd steps of config B on {n_windows} windows each (32ch x {T}), fp32 torch CPU ops, "
+                      f"{dt:.1f} s on {threads} threads"}
 
 
 def main():
@@ -163,6 +166,20 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
+    timing_mode = "HIP events around every conv launch inside the timed region (eager launches)"
+    if graphed is not None and not args.no_kernel_timing:
+        # A replayed HIP graph has no host-visible launch boundaries, so the per-kernel durations are taken
+        # from eager launches of the SAME step (same tensors, same kernels, same stream) right after the timed
+        # region; profiles/ holds the rocprofv3 summary of the graph replay itself for cross-checking.
+        ops.PROFILE = []
+        for _ in range(min(3, args.steps)):
+            loss_fn(model(ob, ids), tgt).backward()
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        prof_steps = min(3, args.steps)
+        timing_mode = "HIP events around every conv launch, eager launches of the same step right after the graph-replayed timed region"
+    else:
+        prof_steps = args.steps
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -192,12 +209,12 @@ def main():
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
         kern = {k: {"launches": v[2], "avg_us": 1e6 * v[1] / v[2], "tflops_algorithmic": v[0] / v[1] / 1e12,
-                    "ms_per_step": 1e3 * v[1] / args.steps} for k, v in agg.items()}
+                    "ms_per_step": 1e3 * v[1] / prof_steps} for k, v in agg.items()}
         dom = agg["conv_fwd"]
         out["roofline"] = {"bound": "mfma", "kernel": "conv_fwd_kernel<bf16> (implicit-GEMM conv forward + data-grad)",
                            "achieved": dom[0] / dom[1] / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": dom[0] / dom[1] / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
-                           "avg_launch_us": 1e6 * dom[1] / dom[2], "launches": dom[2]}
+                           "avg_launch_us": 1e6 * dom[1] / dom[2], "launches": dom[2], "timing": timing_mode}
         out["kernels"] = kern
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_windows)
