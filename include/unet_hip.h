@@ -171,6 +171,54 @@ int unet_gated_add_bwd(int32_t dtype, const void* o, const void* dout, const flo
 int unet_colsum(int32_t dtype, const void* x, float* out_part, int32_t n, int32_t rows, int32_t c,
                 void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Loss / evaluation reductions (csrc/metrics.hip).  Inputs are NCL rows: row r starts at
+ * base + r*ld (elements), time is the contiguous axis.  fp64 results, no host sync.
+ * ---------------------------------------------------------------------------------- */
+
+/* train.py:941-952 pooled statistics + models.py:4262-4287 / 4331-4362 per-row moments, over t in [lo,hi):
+ * out_rows[r][8] = { n, S t, S t^2, S p, S p^2, S p*t, S (p-t)^2, S |p-t| }  (order of train.py:1076-1085) */
+int unet_pair_moments(int32_t dtype, const void* pred, const void* target, int64_t rows, int64_t ld_pred,
+                      int64_t ld_target, int32_t lo, int32_t hi, double* out_rows, void* stream);
+/* out[k] = sum_r in[r][k], k < width <= 64: the cross-row totals of the above (deterministic) */
+int unet_sum_rows_f64(const double* in, int64_t rows, int32_t width, double* out, void* stream);
+
+/* train.py:1481-1486 backward of  w * F.l1_loss(crop(pred), crop(target)):
+ * dpred[r][i] = gscale[0]*mul*sign(pred-target) for lo <= i < hi, else 0  (dense [rows][t], grad_dtype) */
+int unet_l1_crop_bwd(int32_t dtype, int32_t grad_dtype, const void* pred, const void* target, int64_t rows,
+                     int64_t ld_pred, int64_t ld_target, int32_t t, int32_t lo, int32_t hi, const float* gscale,
+                     float mul, void* dpred, void* stream);
+
+/* per-row z-score y = (x-mean)/den of dense rows [rows][t] in one HBM pass:
+ * mode 0: den = std+eps (models.py:3235 unbiased=1; data.py:3121,4649 unbiased=0);
+ * mode 1: den = max(std,eps) (train.py:476-495 per_channel_normalize, unbiased=1) */
+int unet_row_zscore(int32_t in_dtype, int32_t out_dtype, const void* x, void* y, int64_t rows, int32_t t, float eps,
+                    int32_t mode, int32_t unbiased, void* stream);
+
+/* Welch PSD of x[r][lo:hi) (models.py:4512-4550; scipy.signal.welch of utils/dsp_metrics.py:163):
+ * segments of nperseg (power of two, 128..2048), hop nperseg/2, periodic Hann, optional constant detrend;
+ * psd[r][k] = scale_k * mean_seg |FFT|^2, k <= nperseg/2, scale_k = edge_scale at DC/Nyquist else scale. */
+int unet_welch_psd(int32_t dtype, const void* x, int64_t rows, int64_t ld, int32_t lo, int32_t hi, int32_t nperseg,
+                   int32_t detrend, float scale, float edge_scale, float* psd, void* stream);
+/* models.py:4611-4627 / 4686-4695: out_rows[r] = { S_k |dB p - dB t|, S_k (dB p - dB t) } over bins [k_lo,k_hi] */
+int unet_psd_db_stats(const float* psd_pred, const float* psd_target, int64_t rows, int32_t nfreq, int32_t k_lo,
+                      int32_t k_hi, int32_t normalize, double* out_rows, void* stream);
+/* band power per row over inclusive bin ranges (host arrays): mode 0 = sum (models.py:4808-4816),
+ * mode 1 = trapezoid*df (np.trapz, utils/dsp_metrics.py:168-177).  out[r][n_bands] */
+int unet_band_power(const float* psd, int64_t rows, int32_t nfreq, int32_t n_bands, const int32_t* lo_host,
+                    const int32_t* hi_host, int32_t mode, float df, float* out, void* stream);
+
+/* phase_five/sliding_window.py:238-251 overlap-average reconstruction.  pred[w][c][window_size] holds windows
+ * first_window .. first_window+n_windows-1 of total_windows (window g starts at g*stride);
+ * mode 0 "average": out[c][n_samples] (+)= their sum per sample (accumulate: add to what out holds, so
+ * chunks / ranks contribute in turn; n_windows may be 0 for a finalize-only call); finalize: divide by
+ * max(count,1), count = windows of the WHOLE recording covering the sample (written to counts if non-NULL).
+ * mode 1 "last" / 2 "first": the sample is written only by the call holding its last / first covering
+ * window, other samples are left untouched (zero-initialise out; chunk sums stay exact). */
+int unet_overlap_add(int32_t dtype, const void* pred, int32_t n_windows, int32_t first_window, int32_t total_windows,
+                     int32_t c, int32_t window_size, int32_t stride, int64_t n_samples, float* out, float* counts,
+                     int32_t accumulate, int32_t finalize, int32_t mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

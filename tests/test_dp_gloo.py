@@ -99,3 +99,44 @@ def test_single_process_is_a_no_op():
     torch.manual_seed(0)
     assert all(p.grad is not None for p in model.parameters())
     assert red.world == 1
+
+
+def _loso_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unet_amd.trainer import run_loso
+    ran = []
+
+    def run_fold(job):
+        ran.append((job.fold_idx, job.seed_idx))
+        return {"val_r2": 0.1 * job.fold_idx + 0.01 * job.seed_idx, "val_corr": 0.5, "val_loss": float(job.run_seed)}
+
+    out = run_loso(["a", "b", "c"], run_fold, seed=42, n_seeds=2)
+    q.put((rank, ran, out["summary"], {k: v["val_r2"] for k, v in out["per_fold"].items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fold_parallel_loso_two_ranks():
+    """LOSO jobs dealt to 2 ranks: every (fold, seed) runs exactly once, both ranks aggregate the same
+    result, equal to the serial (reference-order) aggregation."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_loso_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, ran, summary, per = q.get(timeout=120)
+        res[rank] = (ran, summary, per)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res[0][0] + res[1][0]) == [(f, s) for f in range(3) for s in range(2)]
+    assert res[0][0] == [(0, 0), (1, 0), (2, 0)] and res[1][0] == [(0, 1), (1, 1), (2, 1)]
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    assert abs(res[0][2][1] - 0.105) < 1e-12
+    assert abs(res[0][1]["mean_r2"] - 0.105) < 1e-12
+    assert abs(res[0][1]["mean_loss"] - (42 + 43 + 44 + 45 + 46 + 47) / 6) < 1e-12

@@ -1,0 +1,116 @@
+"""GPU: sliding-window inference (device overlap-average) against the reference's own reconstruction
+(tests/golden/overlap_add.npz), the Trainer step against the oracle's training-step loss, and config C
+(wide ECoG, deeper encoder) against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class Toy(torch.nn.Module):
+    """the stand-in model oracle/make_golden_host.py ran through the reference's continuous_inference"""
+    out_channels = 3
+
+    def forward(self, x):
+        ramp = torch.linspace(-1, 1, x.shape[-1]).to(x.device)   # CPU linspace, as in the generator
+        return x * 0.5 + ramp * x.roll(1, dims=1)
+
+
+@pytest.mark.parametrize("batch", [1, 4, 64])
+def test_continuous_inference_matches_reference(batch):
+    from unet_amd.infer import continuous_inference
+    z = np.load(os.path.join(GD, "overlap_add.npz"))
+    rec = continuous_inference(Toy(), z["signal"], 4096, 1024, batch_windows=batch)
+    assert rec.shape == z["recon"].shape and rec.dtype == np.float32
+    err = np.abs(rec - z["recon"]).max()
+    assert err < 2e-6, err
+    # uncovered tail stays exactly zero (reference behaviour)
+    nw = (14000 - 4096) // 1024 + 1
+    assert np.all(rec[:, (nw - 1) * 1024 + 4096:] == 0)
+
+
+@pytest.mark.parametrize("mode", ["average", "last", "first"])
+def test_overlap_modes_and_chunking_vs_oracle(mode):
+    from oracle import metrics_oracle as MO
+    from unet_amd.infer import overlap_add
+    rng = np.random.default_rng(5)
+    nw, c, w, s = 9, 2, 300, 70
+    n = (nw - 1) * s + w + 13
+    preds = rng.standard_normal((nw, c, w)).astype(np.float32)
+    out = torch.zeros((c, n), device="cuda")
+    pt = torch.from_numpy(preds).cuda()
+    for a, b in [(0, 4), (4, 5), (5, 9)]:          # three chunks, as three ranks / batches would contribute
+        overlap_add(pt[a:b], a, nw, s, out, True, False, mode)
+    if mode == "average":
+        overlap_add(None, 0, nw, s, out, True, True, window_size=w)
+        ref = MO.overlap_average(preds, n, s)
+    else:
+        ref = np.zeros((c, n), dtype=np.float32)
+        order = range(nw) if mode == "last" else reversed(range(nw))
+        for i in order:
+            ref[:, i * s:i * s + w] = preds[i]
+    assert np.allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_short_recording_gives_zeros():
+    from unet_amd.infer import continuous_inference
+    rec = continuous_inference(Toy(), np.ones((3, 100), np.float32), 4096, 1024)
+    assert rec.shape == (3, 100) and not rec.any()
+
+
+def test_trainer_step_matches_oracle_and_learns():
+    import unet_amd
+    from oracle import condunet_oracle as O
+    from unet_amd.trainer import Trainer
+    cfg = dict(in_channels=8, out_channels=8, base=16, emb_dim=32, conv_type="modern", attention_type="none", activation="gelu")
+    sd = O.init_state_dict(cfg, seed=3)
+    g = torch.Generator().manual_seed(0)
+    ob, tgt = torch.randn(4, 8, 4608, generator=g), torch.randn(4, 8, 4608, generator=g) * 2 + 1
+    ids = torch.tensor([0, 1, 2, 3])
+    ref_loss = float(O.train_step_loss(sd, cfg, ob, tgt, odor_ids=ids))
+    model = unet_amd.CondUNet1D(**cfg).cuda()
+    model.load_state_dict(sd, strict=True)
+    tr = Trainer(model, lr=1e-3, compute_dtype=torch.float32, nan_check_every=1)
+    first = float(tr.step(ob.cuda(), tgt.cuda(), ids.cuda()))
+    assert abs(first - ref_loss) < 1e-4
+    for _ in range(8):
+        last = float(tr.step(ob.cuda(), tgt.cuda(), ids.cuda()))
+    assert last < first
+    res = tr.evaluate([(ob.cuda(), tgt.cuda(), ids.cuda())], fast_mode=False)
+    assert set(("mse", "mae", "corr", "r2", "psd_err_db", "psd_diff_db", "loss")) <= set(res)
+    assert abs(res["loss"] - res["mae"]) < 1e-12
+    with pytest.raises(ValueError, match="NaN/Inf"):
+        tr.step(ob.cuda() * float("nan"), tgt.cuda(), ids.cuda())
+
+
+def test_config_c_wide_deep_vs_oracle():
+    """BASELINE configs[2] shape family: 128 input/output channels, n_downsample=4 (channel ladder capped at
+    8*base), at a base the oracle finishes in seconds."""
+    import torch.nn.functional as F
+    import unet_amd
+    from oracle import condunet_oracle as O
+    cfg = dict(in_channels=128, out_channels=128, base=32, conv_type="modern", attention_type="none", activation="gelu",
+               n_downsample=4)
+    sd = O.init_state_dict(cfg, seed=5)
+    g = torch.Generator().manual_seed(1)
+    ob, tgt = torch.randn(2, 128, 1024, generator=g), torch.randn(2, 128, 1024, generator=g)
+    ids = torch.tensor([2, 5])
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    run_sd = dict(sd)
+    run_sd.update(leaves)
+    ref = O.forward(run_sd, cfg, ob, odor_ids=ids, training=True)
+    F.l1_loss(ref[..., 100:900], tgt[..., 100:900]).backward()
+    model = unet_amd.CondUNet1D(**cfg).cuda()
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    out = model(ob.cuda(), ids.cuda())
+    F.l1_loss(out[..., 100:900], tgt.cuda()[..., 100:900]).backward()
+    rel = lambda a, b: ((a.double().cpu() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    assert rel(out, ref) < 1e-4
+    worst = max(rel(p.grad, leaves[k].grad) for k, p in model.named_parameters()
+                if leaves[k].grad is not None and leaves[k].grad.norm() > 1e-7)
+    assert worst < 1e-3, worst

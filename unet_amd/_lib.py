@@ -63,6 +63,14 @@ _SIGNATURES = {
     "unet_film_softmax_bwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + _row_args),
     "unet_gated_add_fwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp] + _row_args),
     "unet_gated_add_bwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp] + _row_args),
+    "unet_pair_moments": (C.c_int, [_i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "unet_sum_rows_f64": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "unet_l1_crop_bwd": (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _f32, _vp, _vp]),
+    "unet_row_zscore": (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i32, _f32, _i32, _i32, _vp]),
+    "unet_welch_psd": (C.c_int, [_i32, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp]),
+    "unet_psd_db_stats": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "unet_band_power": (C.c_int, [_vp, _i64, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), _i32, _f32, _vp, _vp]),
+    "unet_overlap_add": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _i32, _vp]),
 }
 
 _lib = None

@@ -30,7 +30,8 @@ class GraphedTrainStep:
 
     def __init__(self, model: torch.nn.Module, loss_fn: Callable, optimizer: torch.optim.Optimizer,
                  inputs: Sequence[torch.Tensor], targets: Sequence[torch.Tensor], clip_norm: Optional[float] = None,
-                 warmup: int = 3, process_group=None, bucket_bytes: int = 64 << 20):
+                 warmup: int = 3, process_group=None, bucket_bytes: int = 64 << 20,
+                 forward: Optional[Callable] = None):
         self.model, self.loss_fn, self.opt, self.clip = model, loss_fn, optimizer, clip_norm
         self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
         self.static_in = [t.clone() for t in inputs]
@@ -39,7 +40,7 @@ class GraphedTrainStep:
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
 
         def fwd_bwd():
-            out = model(*self.static_in)
+            out = (forward or model)(*self.static_in)
             loss = loss_fn(out, *self.static_tg)
             loss.backward()
             return loss

@@ -1,0 +1,153 @@
+"""Data-parallel training step, evaluation and LOSO fold scheduling on the HIP path.
+
+Reproduces the per-batch semantics of the reference's ``train_epoch`` (train.py:1395-1560) and the pooled
+metrics of ``evaluate`` (train.py:776-1291) for the model in scope:
+
+    pcx = per_channel_normalize(pcx)                     train.py:1405
+    pred = model(ob, odor | cond_emb=...)                train.py:1462-1464
+    loss = weight_l1 * F.l1_loss(crop(pred), crop(pcx))  train.py:1481-1486
+    loss.backward()  (bucketed RCCL all-reduce overlapped, replaces DDP)   train.py:1546, 2161-2181
+    clip_grad_norm_(5.0); AdamW.step(); zero_grad(set_to_none)              train.py:1553-1560
+
+One process per GPU (``torchrun``); ``Trainer`` picks up ``torch.distributed`` if it is initialised.
+The NaN/Inf abort of train.py:1543 is kept but checked on the device and read every ``nan_check_every``
+steps instead of syncing the host every step.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import metrics
+from .dp import BucketedGradAllReduce, broadcast_parameters
+from .folds import LOSOJob, aggregate_folds, aggregate_seed_results, assign_jobs, loso_jobs
+
+GRAD_CLIP = 5.0                                             # train.py:235
+DEFAULT_BETAS = (0.7595905764360957, 0.920298282605139)     # train.py:186-188
+
+
+class Trainer:
+    def __init__(self, model: torch.nn.Module, lr: float = 2e-4, betas=DEFAULT_BETAS, weight_decay: float = 0.0,
+                 weight_l1: float = 1.0, grad_clip: float = GRAD_CLIP, compute_dtype: Optional[torch.dtype] = torch.bfloat16,
+                 use_graph: bool = False, bucket_bytes: int = 64 << 20, nan_check_every: int = 50, process_group=None):
+        self.model = model
+        if compute_dtype is not None and hasattr(model, "set_compute_dtype"):
+            model.set_compute_dtype(compute_dtype)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        broadcast_parameters(model, process_group=process_group)
+        self.weight_l1, self.grad_clip = weight_l1, grad_clip
+        self.use_graph = use_graph
+        self.opt = torch.optim.AdamW(model.parameters(), lr=lr, betas=betas, weight_decay=weight_decay, fused=True,
+                                     capturable=use_graph)
+        self.reducer = None if use_graph else BucketedGradAllReduce(model.parameters(), bucket_bytes, process_group)
+        self._graphed = None
+        self._bucket_bytes = bucket_bytes
+        self.nan_check_every = nan_check_every
+        self._steps = 0
+        self._bad = None
+
+    def _loss(self, pred, target):
+        return metrics.l1_crop_loss(pred, target, self.weight_l1)
+
+    def step(self, ob: torch.Tensor, target: torch.Tensor, odor_ids: Optional[torch.Tensor] = None,
+             cond_emb: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One optimisation step on a batch of windows; returns the (device) loss."""
+        self.model.train()
+        tgt = metrics.per_channel_normalize(target)
+        if self.use_graph:
+            cond = [cond_emb] if cond_emb is not None else ([odor_ids] if odor_ids is not None else [])
+            if self._graphed is None:
+                from .graphs import GraphedTrainStep
+                if cond_emb is not None:
+                    fwd = lambda o, e: self.model(o, cond_emb=e)
+                else:
+                    fwd = lambda o, *i: self.model(o, *i)
+                self._graphed = GraphedTrainStep(self.model, self._loss, self.opt, [ob] + cond, [tgt],
+                                                 clip_norm=self.grad_clip, process_group=self.pg,
+                                                 bucket_bytes=self._bucket_bytes, forward=fwd)
+            loss = self._graphed([ob] + cond, [tgt])
+        else:
+            self.reducer.zero_grad()
+            pred = self.model(ob, odor_ids, cond_emb=cond_emb) if cond_emb is not None else self.model(ob, odor_ids)
+            loss = self._loss(pred, tgt)
+            loss.backward()
+            self.reducer.finish()
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip)
+            self.opt.step()
+        bad = ~torch.isfinite(loss.detach())
+        self._bad = bad if self._bad is None else (self._bad | bad)
+        self._steps += 1
+        if self._steps % self.nan_check_every == 0:
+            self.check_finite()
+        return loss
+
+    def check_finite(self):
+        if self._bad is not None and bool(self._bad):
+            raise ValueError("NaN/Inf detected in loss")          # train.py:1543-1544
+        self._bad = None
+
+    @torch.no_grad()
+    def evaluate(self, batches: Iterable[Sequence[torch.Tensor]], fast_mode: bool = True,
+                 sampling_rate: float = 1000.0) -> Dict[str, float]:
+        """Pooled metrics of train.py:776-1291 over an iterable of (ob, target, odor_ids | None) batches."""
+        self.model.eval()
+        stats = None
+        psd_err, psd_diff, diag = [], [], None
+        for batch in batches:
+            ob, target = batch[0], batch[1]
+            ids = batch[2] if len(batch) > 2 else None
+            tgt = metrics.per_channel_normalize(target)
+            pred = self.model(ob, ids)
+            pc, tc = metrics.crop_to_target_torch(pred).float(), metrics.crop_to_target_torch(tgt).float()
+            if stats is None:
+                stats = metrics.PooledStats(ob.device)
+            stats.update(pc, tc)
+            if not fast_mode:
+                psd_err.append(metrics.psd_error_db_torch(pc, tc, fs=sampling_rate))
+                psd_diff.append(metrics.psd_diff_db_torch(pc, tc, fs=sampling_rate))
+                if diag is None:
+                    diag = metrics.psd_diagnostics_torch(pc, tc, fs=sampling_rate)
+        if stats is None:
+            return {"mse": 0.0, "mae": 0.0, "corr": 0.0, "r2": 0.0}           # train.py:1061-1068
+        stats.all_reduce(self.pg)
+        out = stats.finalize()
+        if psd_err:
+            out["psd_err_db"] = float(torch.stack(psd_err).mean())
+            out["psd_diff_db"] = float(torch.stack(psd_diff).mean())
+            out["psd_diagnostics"] = diag
+        out["loss"] = self.weight_l1 * out["mae"]                               # train.py:1271-1282
+        return out
+
+
+def run_loso(all_sessions: Sequence[str], run_fold: Callable[[LOSOJob], Dict[str, float]], seed: int = 42,
+             n_seeds: int = 3, folds_to_run: Optional[Sequence[int]] = None, process_group=None) -> Dict[str, object]:
+    """Fold-parallel LOSO (LOSO/runner.py:1046-1177 runs the same jobs serially, one subprocess each).
+
+    Every rank builds the SAME job list (reference order and seeds), takes queue ``rank`` of
+    ``assign_jobs`` and calls ``run_fold(job)`` -> ``{"val_r2", "val_corr", "val_loss"}`` (the
+    test_avg_r2 / test_avg_corr / test_avg_delta of the results JSON, LOSO/runner.py:831-833).  Results
+    are exchanged once (all_gather_object, host side) and aggregated as the reference does:
+    mean over seeds per fold, then mean +- std over folds.
+    """
+    world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(process_group) if world > 1 else 0
+    jobs = loso_jobs(all_sessions, seed, n_seeds, folds_to_run)
+    mine = assign_jobs(jobs, world)[rank]
+    local = [((j.fold_idx, j.seed_idx), run_fold(j)) for j in mine]
+    if world > 1:
+        gathered: List[object] = [None] * world
+        dist.all_gather_object(gathered, local, group=process_group)
+        local = [x for part in gathered for x in part]
+    res = dict(local)
+    folds = sorted({j.fold_idx for j in jobs})
+    per_fold = {}
+    for f in folds:
+        rs = [res[(f, s)] for s in range(n_seeds) if (f, s) in res]
+        per_fold[f] = aggregate_seed_results([r.get("val_r2") for r in rs], [r.get("val_corr") for r in rs],
+                                             [r.get("val_loss") for r in rs])
+    summary = aggregate_folds([per_fold[f]["val_r2"] for f in folds], [per_fold[f]["val_corr"] for f in folds],
+                              [per_fold[f]["val_loss"] for f in folds])
+    return {"jobs": jobs, "per_fold": per_fold, "summary": summary}
