@@ -133,6 +133,8 @@ int unet_bn_finalize_bwd(const float* g1_part, const float* g2_part, int32_t n, 
                          float* cb, float* cc, float* dgamma, float* dbeta, void* stream);
 /* out[c] = sum_r in[r][c]  (fp64 accumulation; second stage of the column-sum partials) */
 int unet_reduce_rows(const float* in, int32_t rows, int32_t c, float* out, void* stream);
+/* out[n][c] = sum_p in[n][p][c]: adds the "part" partials of each window */
+int unet_reduce_parts(const float* in, int32_t n, int32_t parts, int32_t c, float* out, void* stream);
 
 /* z = act(a[n][c]*y + b[n][c]); pool_part = partial sum_t z  (norm-apply + GELU + SE squeeze,
  * models.py:559-560, 827, 649/660).  pool_part may be NULL. */

@@ -105,11 +105,26 @@ template <> struct VecIO<float, 4> {
 };
 
 // ---- activations (models.py:59-65) and their derivatives ------------------------------------
+// Exact-form GELU (nn.GELU(): 0.5 x (1 + erf(x/sqrt 2))) without libm's erff: the streaming kernels are
+// HBM-bound only if the per-element math stays ~15 VALU ops.  Phi(x) via the Abramowitz-Stegun 7.1.26
+// rational form of erfc (|error| <= 1.5e-7, evaluated on |x| so there is no cancellation in the negative
+// tail); e = exp(-x^2/2) is shared with the derivative's density term.
+__device__ __forceinline__ void gelu_cdf(float x, float& cdf, float& e) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+  e = __expf(-z * z);
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float hq = 0.5f * p * t * e;          // 0.5 * erfc(|x|/sqrt 2)
+  cdf = x >= 0.f ? 1.f - hq : hq;
+}
 __device__ __forceinline__ float act_fwd(int act, float x) {
   switch (act) {
     case UNET_ACT_RELU: return x > 0.f ? x : 0.f;
     case UNET_ACT_LEAKY: return x > 0.f ? x : 0.2f * x;
-    case UNET_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    case UNET_ACT_GELU: { float c, e; gelu_cdf(x, c, e); return x * c; }
     case UNET_ACT_SILU: return x / (1.f + __expf(-x));
     case UNET_ACT_MISH: {
       float sp = x > 20.f ? x : log1pf(__expf(x));
@@ -122,9 +137,7 @@ __device__ __forceinline__ float act_bwd(int act, float x) {
   switch (act) {
     case UNET_ACT_RELU: return x > 0.f ? 1.f : 0.f;
     case UNET_ACT_LEAKY: return x > 0.f ? 1.f : 0.2f;
-    case UNET_ACT_GELU:
-      return 0.5f * (1.f + erff(x * 0.70710678118654752f)) +
-             x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    case UNET_ACT_GELU: { float c, e; gelu_cdf(x, c, e); return fmaf(x * 0.3989422804014327f, e, c); }
     case UNET_ACT_SILU: {
       float s = 1.f / (1.f + __expf(-x));
       return s * (1.f + x * (1.f - s));

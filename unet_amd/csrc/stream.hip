@@ -425,86 +425,146 @@ __global__ __launch_bounds__(THREADS) void film_softmax_bwd_kernel(const T* q, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// BatchNorm (training) statistics finalisation: one launch replaces ~30 tiny tensor ops.
-// block = 64 channels x 4 segments of the (window, part) range; fp64 accumulation.
+// Column sums over partial rows.  The partial buffers are [rows = n*parts][c] fp32 with rows in the
+// thousands; a block owns CS_CH = 32 channels and spreads the rows over CS_SEG = 32 row segments
+// (1024 threads), each thread keeping 8 independent loads in flight, so the reduction is bandwidth-
+// not latency-bound.  fp64 accumulation; result of column (ch0 + cl) returned to the threads with seg == 0.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* s1p, const float* s2p, int n, int parts, int c,
-                                                              double count, float eps, const float* gamma,
-                                                              const float* beta, float* run_mean, float* run_var,
-                                                              float momentum, float* mean_o, float* rstd_o, float* a_o,
-                                                              float* b_o) {
-  __shared__ double red[2][4][64];
-  const int cl = threadIdx.x & 63, seg = threadIdx.x >> 6;
-  const int ch = blockIdx.x * 64 + cl;
-  const int total = n * parts;
-  double a1 = 0.0, a2 = 0.0;
-  if (ch < c)
-    for (int i = seg; i < total; i += 4) { a1 += s1p[(long long)i * c + ch]; a2 += s2p[(long long)i * c + ch]; }
-  red[0][seg][cl] = a1; red[1][seg][cl] = a2;
+constexpr int CS_CH = 32, CS_SEG = 32, CS_THREADS = CS_CH * CS_SEG;
+
+template <int K>
+__device__ __forceinline__ void column_sums(const float* const (&src)[K], int rows, int c, int ch, double (&out)[K],
+                                            double* red /* [K][CS_SEG][CS_CH] */) {
+  const int cl = threadIdx.x % CS_CH, seg = threadIdx.x / CS_CH;
+  double acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = 0.0;
+  if (ch < c) {
+    int r = seg;
+    for (; r + 7 * CS_SEG < rows; r += 8 * CS_SEG) {
+      float v[K][8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k][u] = src[k][(long long)(r + u * CS_SEG) * c + ch];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] += v[k][u];
+    }
+    for (; r < rows; r += CS_SEG)
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] += src[k][(long long)r * c + ch];
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) red[(k * CS_SEG + seg) * CS_CH + cl] = acc[k];
+  __syncthreads();
+  if (seg == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double sum = 0.0;
+      for (int j = 0; j < CS_SEG; ++j) sum += red[(k * CS_SEG + j) * CS_CH + cl];
+      out[k] = sum;
+    }
+  }
+}
+
+// BatchNorm (training) statistics finalisation: one launch replaces ~30 tiny tensor ops.
+__global__ __launch_bounds__(CS_THREADS) void bn_finalize_fwd_kernel(const float* s1p, const float* s2p, int n, int parts, int c,
+                                                                     double count, float eps, const float* gamma,
+                                                                     const float* beta, float* run_mean, float* run_var,
+                                                                     float momentum, float* mean_o, float* rstd_o, float* a_o,
+                                                                     float* b_o) {
+  __shared__ double red[2 * CS_SEG * CS_CH];
+  __shared__ float coef[4][CS_CH];
+  const int cl = threadIdx.x % CS_CH, seg = threadIdx.x / CS_CH;
+  const int ch = blockIdx.x * CS_CH + cl;
+  const float* const src[2] = {s1p, s2p};
+  double s[2];
+  column_sums<2>(src, n * parts, c, ch, s, red);
+  if (seg == 0 && ch < c) {
+    const double mean = s[0] / count;
+    double var = s[1] / count - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    if (run_mean) {
+      const double unb = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
+      run_mean[ch] = (float)((1.0 - momentum) * run_mean[ch] + momentum * mean);
+      run_var[ch] = (float)((1.0 - momentum) * run_var[ch] + momentum * unb);
+    }
+    const double g = gamma ? (double)gamma[ch] : 1.0, bt = beta ? (double)beta[ch] : 0.0;
+    coef[0][cl] = (float)mean; coef[1][cl] = (float)rstd;
+    coef[2][cl] = (float)(rstd * g); coef[3][cl] = (float)(bt - mean * rstd * g);
+  }
   __syncthreads();
   if (ch >= c) return;
-  const double s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-  const double s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-  const double mean = s1 / count;
-  double var = s2 / count - mean * mean;
-  var = var > 0.0 ? var : 0.0;
-  const double rstd = 1.0 / sqrt(var + (double)eps);
-  if (seg == 0 && run_mean) {
-    const double unb = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
-    run_mean[ch] = (float)((1.0 - momentum) * run_mean[ch] + momentum * mean);
-    run_var[ch] = (float)((1.0 - momentum) * run_var[ch] + momentum * unb);
-  }
-  const double g = gamma ? (double)gamma[ch] : 1.0, bt = beta ? (double)beta[ch] : 0.0;
-  const float a = (float)(rstd * g), b = (float)(bt - mean * rstd * g);
-  for (int i = seg; i < n; i += 4) {
+  const float m = coef[0][cl], r = coef[1][cl], a = coef[2][cl], b = coef[3][cl];
+  for (int i = seg; i < n; i += CS_SEG) {
     const long long o = (long long)i * c + ch;
-    mean_o[o] = (float)mean; rstd_o[o] = (float)rstd; a_o[o] = a; b_o[o] = b;
+    mean_o[o] = m; rstd_o[o] = r; a_o[o] = a; b_o[o] = b;
   }
 }
 
 // backward: dgamma, dbeta and the per-(window, channel) coefficients of  dy = ca*g + cb*y + cc
-__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* g1p, const float* g2p, int n, int parts, int c,
-                                                              double count, const float* mean_i, const float* rstd_i,
-                                                              const float* gamma, float* ca_o, float* cb_o, float* cc_o,
-                                                              float* dgamma, float* dbeta) {
-  __shared__ double red[2][4][64];
-  const int cl = threadIdx.x & 63, seg = threadIdx.x >> 6;
-  const int ch = blockIdx.x * 64 + cl;
-  const int total = n * parts;
-  double a1 = 0.0, a2 = 0.0;
-  if (ch < c)
-    for (int i = seg; i < total; i += 4) { a1 += g1p[(long long)i * c + ch]; a2 += g2p[(long long)i * c + ch]; }
-  red[0][seg][cl] = a1; red[1][seg][cl] = a2;
-  __syncthreads();
-  if (ch >= c) return;
-  const double g1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-  const double g2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
-  const double mean = mean_i[ch], rstd = rstd_i[ch];   // row 0 of the [n][c] arrays (identical for all windows)
-  const double gm = gamma ? (double)gamma[ch] : 1.0;
-  const double gy = rstd * (g2 - mean * g1);           // sum g * yhat
-  if (seg == 0) {
+__global__ __launch_bounds__(CS_THREADS) void bn_finalize_bwd_kernel(const float* g1p, const float* g2p, int n, int parts, int c,
+                                                                     double count, const float* mean_i, const float* rstd_i,
+                                                                     const float* gamma, float* ca_o, float* cb_o, float* cc_o,
+                                                                     float* dgamma, float* dbeta) {
+  __shared__ double red[2 * CS_SEG * CS_CH];
+  __shared__ float coef[3][CS_CH];
+  const int cl = threadIdx.x % CS_CH, seg = threadIdx.x / CS_CH;
+  const int ch = blockIdx.x * CS_CH + cl;
+  const float* const src[2] = {g1p, g2p};
+  double s[2];
+  column_sums<2>(src, n * parts, c, ch, s, red);
+  if (seg == 0 && ch < c) {
+    const double g1 = s[0], g2 = s[1];
+    const double mean = mean_i[ch], rstd = rstd_i[ch];   // row 0 of the [n][c] arrays (identical for all windows)
+    const double gm = gamma ? (double)gamma[ch] : 1.0;
+    const double gy = rstd * (g2 - mean * g1);           // sum g * yhat
     if (dgamma) dgamma[ch] = (float)gy;
     if (dbeta) dbeta[ch] = (float)g1;
+    const double m1 = gm * g1 / count, m2 = gm * gy / count;
+    coef[0][cl] = (float)(rstd * gm); coef[1][cl] = (float)(-rstd * rstd * m2);
+    coef[2][cl] = (float)(-rstd * m1 + rstd * rstd * mean * m2);
   }
-  const double m1 = gm * g1 / count, m2 = gm * gy / count;
-  const float ca = (float)(rstd * gm), cb = (float)(-rstd * rstd * m2), cc = (float)(-rstd * m1 + rstd * rstd * mean * m2);
-  for (int i = seg; i < n; i += 4) {
+  __syncthreads();
+  if (ch >= c) return;
+  const float ca = coef[0][cl], cb = coef[1][cl], cc = coef[2][cl];
+  for (int i = seg; i < n; i += CS_SEG) {
     const long long o = (long long)i * c + ch;
     ca_o[o] = ca; cb_o[o] = cb; cc_o[o] = cc;
   }
 }
 
 // out[c] = sum over rows of in[rows][c]   (second stage of the per-part column sums)
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* in, int rows, int c, float* out) {
-  __shared__ double red[4][64];
-  const int cl = threadIdx.x & 63, seg = threadIdx.x >> 6;
-  const int ch = blockIdx.x * 64 + cl;
-  double a = 0.0;
-  if (ch < c)
-    for (int i = seg; i < rows; i += 4) a += in[(long long)i * c + ch];
-  red[seg][cl] = a;
-  __syncthreads();
-  if (ch < c && seg == 0) out[ch] = (float)(red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+__global__ __launch_bounds__(CS_THREADS) void reduce_rows_kernel(const float* in, int rows, int c, float* out) {
+  __shared__ double red[CS_SEG * CS_CH];
+  const int ch = blockIdx.x * CS_CH + threadIdx.x % CS_CH;
+  const float* const src[1] = {in};
+  double s[1];
+  column_sums<1>(src, rows, c, ch, s, red);
+  if (threadIdx.x / CS_CH == 0 && ch < c) out[ch] = (float)s[0];
+}
+
+// out[n][c] = sum_p in[n][p][c]   (adds the per-row-chunk partials of one window; replaces a strided
+// torch reduction over the middle axis)
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* in, int parts, int c, float* out) {
+  const int n = blockIdx.y;
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  const float* p = in + (long long)n * parts * c + ch;
+  float a = 0.f;
+  int r = 0;
+  for (; r + 7 < parts; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(long long)(r + u) * c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += v[u];
+  }
+  for (; r < parts; ++r) a += p[(long long)r * c];
+  out[(long long)n * c + ch] = a;
 }
 
 template <typename T, int V>
@@ -827,7 +887,7 @@ extern "C" int unet_bn_finalize_fwd(const float* s1_part, const float* s2_part, 
   UNET_REQUIRE(s1_part && s2_part && mean && rstd && a && b && n > 0 && parts > 0 && c > 0 && rows > 0,
                "bn_finalize_fwd: bad arguments");
   UNET_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_fwd: running stats must come in pairs");
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, 64)), dim3(256), 0, static_cast<hipStream_t>(stream), s1_part,
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, CS_CH)), dim3(CS_THREADS), 0, static_cast<hipStream_t>(stream), s1_part,
                      s2_part, n, parts, c, (double)n * rows, eps, gamma, beta, running_mean, running_var, momentum, mean,
                      rstd, a, b);
   UNET_LAUNCH_CHECK("bn_finalize_fwd");
@@ -839,7 +899,7 @@ extern "C" int unet_bn_finalize_bwd(const float* g1_part, const float* g2_part, 
                                     float* cb, float* cc, float* dgamma, float* dbeta, void* stream) {
   UNET_REQUIRE(g1_part && g2_part && mean && rstd && ca && cb && cc && n > 0 && parts > 0 && c > 0 && rows > 0,
                "bn_finalize_bwd: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, 64)), dim3(256), 0, static_cast<hipStream_t>(stream), g1_part,
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(c, CS_CH)), dim3(CS_THREADS), 0, static_cast<hipStream_t>(stream), g1_part,
                      g2_part, n, parts, c, (double)n * rows, mean, rstd, gamma, ca, cb, cc, dgamma, dbeta);
   UNET_LAUNCH_CHECK("bn_finalize_bwd");
   return 0;
@@ -847,7 +907,14 @@ extern "C" int unet_bn_finalize_bwd(const float* g1_part, const float* g2_part, 
 
 extern "C" int unet_reduce_rows(const float* in, int32_t rows, int32_t c, float* out, void* stream) {
   UNET_REQUIRE(in && out && rows > 0 && c > 0, "reduce_rows: bad arguments");
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(c, 64)), dim3(256), 0, static_cast<hipStream_t>(stream), in, rows, c, out);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(c, CS_CH)), dim3(CS_THREADS), 0, static_cast<hipStream_t>(stream), in, rows, c, out);
   UNET_LAUNCH_CHECK("reduce_rows");
+  return 0;
+}
+
+extern "C" int unet_reduce_parts(const float* in, int32_t n, int32_t parts, int32_t c, float* out, void* stream) {
+  UNET_REQUIRE(in && out && n > 0 && n <= 65535 && parts > 0 && c > 0, "reduce_parts: bad arguments");
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(c, 256), n), dim3(256), 0, static_cast<hipStream_t>(stream), in, parts, c, out);
+  UNET_LAUNCH_CHECK("reduce_parts");
   return 0;
 }

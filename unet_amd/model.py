@@ -175,14 +175,10 @@ class FiLM(nn.Module):
         if self.cond_mode == "none" or emb is None:
             return x
         emb = emb.float()
-        g1 = ops.geom_conv(1)
-        l = x.shape[1]
-        q = ops.conv(x, self.q_proj.weight.permute(2, 0, 1), self.q_proj.bias, g1, l)
         kk = self.k_proj(emb) * self.scale_factor
         v = self.v_proj(emb)
-        h = ops.FilmSoftmaxFn.apply(q, kk, v)
-        o = ops.conv(h, self.out_proj.weight.permute(2, 0, 1), self.out_proj.bias, g1, l)
-        return ops.GatedAddFn.apply(x, o, self.gate(emb))
+        return ops.FilmFn.apply(x, self.q_proj.weight.permute(2, 0, 1), self.q_proj.bias,
+                                self.out_proj.weight.permute(2, 0, 1), self.out_proj.bias, kk, v, self.gate(emb))
 
     def forward(self, x: Tensor, emb: Optional[Tensor] = None) -> Tensor:
         if self.cond_mode == "none" or emb is None:

@@ -218,6 +218,31 @@ def conv_forward_raw(geom: ConvGeom, x1: Tensor, x2: Optional[Tensor], w_packed:
     return y
 
 
+def conv_wgrad_raw(geom: ConvGeom, x1: Tensor, x2: Optional[Tensor], dy: Tensor, c_out: int) -> Tensor:
+    """dW[j][co][ci] (fp32) of the conv described by geom, from its input(s) and the output gradient."""
+    lib = _lib.load()
+    n = x1.shape[0]
+    ctot = x1.shape[2] + (x2.shape[2] if x2 is not None else 0)
+    d = _desc(geom, x1, x2, dy, None)
+    ws_bytes = lib.unet_conv1d_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=dy.device)
+    dw = torch.empty((geom.n_taps, c_out, ctot), dtype=torch.float32, device=dy.device)
+    with _Timed("conv_wgrad", geom.alg_flops(n, dy.shape[1], c_out, ctot)):
+        check(lib.unet_conv1d_wgrad(C.byref(d), _p(x1), _p(x2), _p(dy), _p(dw), _p(ws), ws_bytes, _stream()),
+              "unet_conv1d_wgrad")
+    return dw
+
+
+def conv_dgrad_raw(geom: ConvGeom, wf: Tensor, dy: Tensor, l_in: int, row_lo: int, rows: int,
+                   res: Optional[Tensor] = None) -> Tensor:
+    """dx[:, :, row_lo:row_lo+rows] of the conv (wf: fp32 [J, Cout, Ctot]); ``res`` is added in the epilogue, which
+    is how a second gradient path into the same tensor is merged without an extra pass."""
+    gd, src = geom.dgrad()
+    j, c_out, _ = wf.shape
+    wp = pack_weights(wf, _dt(dy), transpose=True, tap_src=src, n_taps=j, row_lo=row_lo, rows=rows, c1=c_out, c2=0)
+    return conv_forward_raw(gd, dy, None, wp, None, res, l_in, rows)
+
+
 class ConvFn(torch.autograd.Function):
     """y = conv(geom; [x1 | x2], w[J, Cout, C1+C2], bias) (+ res).  See include/unet_hip.h."""
 
@@ -247,11 +272,9 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        lib = _lib.load()
         x1, x2, wf = ctx.saved_tensors
         geom: ConvGeom = ctx.geom
         dy = dy.contiguous()
-        dt = _dt(dy)
         n, l_in, c1 = x1.shape
         c2 = x2.shape[2] if x2 is not None else 0
         j, c_out, ctot = wf.shape
@@ -261,25 +284,13 @@ class ConvFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[3]:
             db = colsum(dy)
         if ctx.needs_input_grad[2]:
-            y_like = dy
-            d = _desc(geom, x1, x2, y_like, None)
-            ws_bytes = lib.unet_conv1d_wgrad_workspace_bytes(C.byref(d))
-            ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=dy.device)
-            dw = torch.empty((j, c_out, ctot), dtype=torch.float32, device=dy.device)
-            with _Timed("conv_wgrad", geom.alg_flops(n, dy.shape[1], c_out, ctot)):
-                check(lib.unet_conv1d_wgrad(C.byref(d), _p(x1), _p(x2), _p(dy), _p(dw), _p(ws), ws_bytes, _stream()),
-                      "unet_conv1d_wgrad")
+            dw = conv_wgrad_raw(geom, x1, x2, dy, c_out)
             if ctx.w_dtype != torch.float32:
                 dw = dw.to(ctx.w_dtype)
-        need1, need2 = ctx.needs_input_grad[0], ctx.has_x2 and ctx.needs_input_grad[1]
-        if need1 or need2:
-            gd, src = geom.dgrad()
-            if need1:
-                wp = pack_weights(wf, dt, transpose=True, tap_src=src, n_taps=j, row_lo=0, rows=c1, c1=c_out, c2=0)
-                dx1 = conv_forward_raw(gd, dy, None, wp, None, None, l_in, c1)
-            if need2:
-                wp = pack_weights(wf, dt, transpose=True, tap_src=src, n_taps=j, row_lo=c1, rows=c2, c1=c_out, c2=0)
-                dx2 = conv_forward_raw(gd, dy, None, wp, None, None, l_in, c2)
+        if ctx.needs_input_grad[0]:
+            dx1 = conv_dgrad_raw(geom, wf, dy, l_in, 0, c1)
+        if ctx.has_x2 and ctx.needs_input_grad[1]:
+            dx2 = conv_dgrad_raw(geom, wf, dy, l_in, c1, c2)
         return dx1, dx2, dw, db, dres, None, None
 
 
@@ -299,6 +310,14 @@ def _dims(x: Tensor):
 def _part_buf(x: Tensor, k: int = 1):
     n, rows, c = x.shape
     return [torch.empty((n, parts(rows), c), dtype=torch.float32, device=x.device) for _ in range(k)]
+
+
+def sum_parts(buf: Tensor) -> Tensor:
+    """[N, parts, C] fp32 partials -> [N, C] (one coalesced HIP pass instead of a strided torch reduction)"""
+    n, p, c = buf.shape
+    out = torch.empty((n, c), dtype=torch.float32, device=buf.device)
+    check(_lib.load().unet_reduce_parts(_p(buf), n, p, c, _p(out), _stream()), "unet_reduce_parts")
+    return out
 
 
 def colsum(x: Tensor) -> Tensor:
@@ -367,7 +386,7 @@ class AffineActFn(torch.autograd.Function):
         check(lib.unet_affine_act_fwd(_dt(y), _p(y), _p(a), _p(b), act_id, _p(z), _p(pbuf), n, rows, c, _stream()),
               "unet_affine_act_fwd")
         if want_pool:
-            pool = pbuf.sum(dim=1)
+            pool = sum_parts(pbuf)
         ctx.stats, ctx.act_id, ctx.want_pool = stats, act_id, want_pool
         ctx.has_affine = gamma is not None
         ctx.save_for_backward(y, a, b, gamma)
@@ -451,7 +470,7 @@ class BatchNormActFn(torch.autograd.Function):
         ctx.gdtype = gamma.dtype if gamma is not None else torch.float32
         ctx.save_for_backward(y, coef, gf)
         if want_pool:
-            return z, pbuf.sum(dim=1)
+            return z, sum_parts(pbuf)
         return z
 
     @staticmethod
@@ -507,7 +526,7 @@ class ScaleFn(torch.autograd.Function):
         (dsp,) = _part_buf(x)
         check(lib.unet_scale_bwd(_dt(x), _p(x), _p(dout), _p(sf), _p(dx), _p(dsp), *_dims(x), _stream()),
               "unet_scale_bwd")
-        return dx, dsp.sum(dim=1).to(ctx.s_dtype)
+        return dx, sum_parts(dsp).to(ctx.s_dtype)
 
 
 class FilmSoftmaxFn(torch.autograd.Function):
@@ -535,7 +554,7 @@ class FilmSoftmaxFn(torch.autograd.Function):
         dkp, dvp = _part_buf(q, 2)
         check(lib.unet_film_softmax_bwd(_dt(q), _p(q), _p(dh), _p(kf), _p(vf), _p(dq), _p(dkp), _p(dvp), *_dims(q),
                                         _stream()), "unet_film_softmax_bwd")
-        return dq, dkp.sum(dim=1).to(ctx.kdt), dvp.sum(dim=1).to(ctx.vdt)
+        return dq, sum_parts(dkp).to(ctx.kdt), sum_parts(dvp).to(ctx.vdt)
 
 
 class GatedAddFn(torch.autograd.Function):
@@ -563,7 +582,62 @@ class GatedAddFn(torch.autograd.Function):
         (dgp,) = _part_buf(o)
         check(lib.unet_gated_add_bwd(_dt(o), _p(o), _p(dout), _p(gf), _p(d_o), _p(dgp), *_dims(o), _stream()),
               "unet_gated_add_bwd")
-        return dout, d_o, dgp.sum(dim=1).to(ctx.gdt)
+        return dout, d_o, sum_parts(dgp).to(ctx.gdt)
+
+
+class FilmFn(torch.autograd.Function):
+    """FiLM.forward (models.py:504-517) as ONE autograd node:
+        q = Wq z + bq;  h = softmax_c(q * kk) * v;  o = Wo h + bo;  out = z + g * o
+    Same kernels as the separate ops; what the fusion buys is the backward: the gradient of the residual
+    path (dout) enters dz through the epilogue of q_proj's data-gradient conv, so autograd never runs a
+    separate full-tensor add, and q / h / o are kept exactly once."""
+
+    @staticmethod
+    def forward(ctx, z, wq, bq, wo, bo, kk, v, g):
+        lib = _lib.load()
+        _need_cuda(z)
+        z = _nlc_ok(z)
+        dt, st = _dt(z), _stream()
+        n, rows, c = z.shape
+        g1 = geom_conv(1)
+        wqf, wof = wq.detach().float(), wo.detach().float()          # [1, C, C] views of the 1x1 conv weights
+        kf, vf, gf = _f32c(kk), _f32c(v), _f32c(g)
+        q = conv_forward_raw(g1, z, None, pack_weights(wqf, dt, transpose=False, tap_src=None, n_taps=1, row_lo=0,
+                                                       rows=c, c1=c, c2=0), _f32c(bq), None, rows, c)
+        h = torch.empty_like(q)
+        check(lib.unet_film_softmax_fwd(dt, _p(q), _p(kf), _p(vf), _p(h), n, rows, c, st), "unet_film_softmax_fwd")
+        o = conv_forward_raw(g1, h, None, pack_weights(wof, dt, transpose=False, tap_src=None, n_taps=1, row_lo=0,
+                                                       rows=c, c1=c, c2=0), _f32c(bo), None, rows, c)
+        out = torch.empty_like(z)
+        check(lib.unet_gated_add_fwd(dt, _p(z), _p(o), _p(gf), _p(out), n, rows, c, st), "unet_gated_add_fwd")
+        ctx.save_for_backward(z, q, h, o, wqf, wof, kf, vf, gf)
+        ctx.dtypes = (wq.dtype, bq.dtype, wo.dtype, bo.dtype, kk.dtype, v.dtype, g.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        z, q, h, o, wqf, wof, kf, vf, gf = ctx.saved_tensors
+        dout = dout.contiguous()
+        dt, st = _dt(z), _stream()
+        n, rows, c = z.shape
+        g1 = geom_conv(1)
+        d_o = torch.empty_like(o)
+        (dgp,) = _part_buf(o)
+        check(lib.unet_gated_add_bwd(dt, _p(o), _p(dout), _p(gf), _p(d_o), _p(dgp), n, rows, c, st), "unet_gated_add_bwd")
+        dwo = conv_wgrad_raw(g1, h, None, d_o, c)
+        dbo = colsum(d_o)
+        dh = conv_dgrad_raw(g1, wof, d_o, rows, 0, c)
+        dq = torch.empty_like(q)
+        dkp, dvp = _part_buf(q, 2)
+        check(lib.unet_film_softmax_bwd(dt, _p(q), _p(dh), _p(kf), _p(vf), _p(dq), _p(dkp), _p(dvp), n, rows, c, st),
+              "unet_film_softmax_bwd")
+        dwq = conv_wgrad_raw(g1, z, None, dq, c)
+        dbq = colsum(dq)
+        dz = conv_dgrad_raw(g1, wqf, dq, rows, 0, c, res=dout) if ctx.needs_input_grad[0] else None
+        t = ctx.dtypes
+        return (dz, dwq.to(t[0]), dbq.to(t[1]), dwo.to(t[2]), dbo.to(t[3]), sum_parts(dkp).to(t[4]),
+                sum_parts(dvp).to(t[5]), sum_parts(dgp).to(t[6]))
 
 
 # ---------------------------------------------------------------------------------------------
