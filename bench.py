@@ -111,12 +111,14 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B = args.batch
     ob = torch.randn(B, 32, T, device=dev, generator=g).to(cdt)
-    tgt = torch.randn(B, 32, T, device=dev, generator=g)
-    tgt = (tgt - tgt.mean(-1, keepdim=True)) / tgt.std(-1, keepdim=True).clamp(min=1e-6)  # train.py:476-495
+    tgt = torch.randn(B, 32, T, device=dev, generator=g) * 1.7 + 0.3     # raw target batch
     ids = torch.zeros(B, dtype=torch.long, device=dev)
 
+    from unet_amd import metrics
+
     def loss_fn(pred, target):
-        return F.l1_loss(pred[..., CROP[0]:CROP[1]].float(), target[..., CROP[0]:CROP[1]])  # train.py:1481-1486
+        # train.py:1405 (target z-score, per batch) + train.py:1481-1486 (L1 on the [500:4500] crop)
+        return metrics.l1_crop_loss(pred, metrics.per_channel_normalize(target), 1.0, CROP[0], CROP[1])
 
     mode = "eager"
     graphed = None

@@ -173,6 +173,18 @@ int unet_gated_add_bwd(int32_t dtype, const void* o, const void* dout, const flo
 int unet_colsum(int32_t dtype, const void* x, float* out_part, int32_t n, int32_t rows, int32_t c,
                 void* stream);
 
+/* Merged-tap weights of the 4-branch dilated conv (models.py:752-759):
+ *   w_eff[t][co][ci] = sum over (b,k) with tap_index_host[b*k_size+k] == t of sw[b] * w_b[co][ci][k]
+ * w_branch_host: host array of n_branch DEVICE pointers to contiguous [co][ci][k] fp32 weights; sw: device [n_branch]
+ * (already softmaxed).  bwd: dw_b[co][ci][k] = sw[b]*dw_eff[t(b,k)][co][ci] and per-block partials of
+ * d sw[b] = <dw_eff[t(b,k)], w_b[..,k]> in dsw_part[unet_merge_taps_parts(co,ci)][n_branch]. */
+int32_t unet_merge_taps_parts(int32_t co, int32_t ci);
+int unet_merge_taps_fwd(const float* const* w_branch_host, const float* sw, int32_t n_branch, int32_t k, int32_t co,
+                        int32_t ci, const int32_t* tap_index_host, int32_t n_taps, float* w_eff, void* stream);
+int unet_merge_taps_bwd(const float* const* w_branch_host, const float* sw, int32_t n_branch, int32_t k, int32_t co,
+                        int32_t ci, const int32_t* tap_index_host, int32_t n_taps, const float* dw_eff,
+                        float* const* dw_branch_host, float* dsw_part, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Loss / evaluation reductions (csrc/metrics.hip).  Inputs are NCL rows: row r starts at
  * base + r*ld (elements), time is the contiguous axis.  fp64 results, no host sync.

@@ -64,6 +64,10 @@ _SIGNATURES = {
     "unet_film_softmax_bwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + _row_args),
     "unet_gated_add_fwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp] + _row_args),
     "unet_gated_add_bwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp] + _row_args),
+    "unet_merge_taps_parts": (_i32, [_i32, _i32]),
+    "unet_merge_taps_fwd": (C.c_int, [C.POINTER(_vp), _vp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _vp, _vp]),
+    "unet_merge_taps_bwd": (C.c_int, [C.POINTER(_vp), _vp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _vp,
+                                      C.POINTER(_vp), _vp, _vp]),
     "unet_pair_moments": (C.c_int, [_i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
     "unet_sum_rows_f64": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "unet_l1_crop_bwd": (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _f32, _vp, _vp]),

@@ -918,3 +918,109 @@ extern "C" int unet_reduce_parts(const float* in, int32_t n, int32_t parts, int3
   UNET_LAUNCH_CHECK("reduce_parts");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Merged-tap weights of MultiScaleDilatedConv1d (models.py:752-759).  The softmax-weighted sum of the
+// parallel dilated branches is one conv whose tap t has  W_eff[t] = sum_{(b,k) -> t} sw[b] * W_b[:, :, k].
+// One thread per (co, ci): reads the B*K branch weights of that pair (K contiguous floats per branch),
+// writes the T merged taps (coalesced across threads).  Backward scatters dW_eff back to the branches
+// and reduces d sw[b] = <dW_eff[t(b,k)], W_b[..., k]> per block (deterministic partials).
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int MT_MAXB = 8, MT_MAXK = 9;
+struct MergeK {
+  const float* w[MT_MAXB];
+  float* dw[MT_MAXB];
+  int tap[MT_MAXB * MT_MAXK];
+  int nb, k, n_taps;
+  long long pairs;   // co * ci
+};
+
+__global__ __launch_bounds__(256) void merge_taps_fwd_kernel(MergeK p, const float* sw, float* w_eff) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.pairs) return;
+  float acc[UNET_MAX_TAPS];
+#pragma unroll
+  for (int t = 0; t < UNET_MAX_TAPS; ++t) acc[t] = 0.f;
+  for (int b = 0; b < p.nb; ++b) {
+    const float s = sw[b];
+    const float* wb = p.w[b] + i * p.k;
+    for (int k = 0; k < p.k; ++k) {
+      const int t = p.tap[b * p.k + k];
+      const float v = s * wb[k];
+      // static indexing keeps acc[] in registers
+#pragma unroll
+      for (int u = 0; u < UNET_MAX_TAPS; ++u) acc[u] += (u == t) ? v : 0.f;
+    }
+  }
+  for (int t = 0; t < p.n_taps; ++t) w_eff[(long long)t * p.pairs + i] = acc[t];
+}
+
+__global__ __launch_bounds__(256) void merge_taps_bwd_kernel(MergeK p, const float* sw, const float* dw_eff, float* dsw_part) {
+  __shared__ float red[MT_MAXB][256 / 64];
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool ok = i < p.pairs;
+  for (int b = 0; b < p.nb; ++b) {
+    float dot = 0.f;
+    if (ok) {
+      const float s = sw[b];
+      const float* wb = p.w[b] + i * p.k;
+      float* dwb = p.dw[b] + i * p.k;
+      for (int k = 0; k < p.k; ++k) {
+        const float g = dw_eff[(long long)p.tap[b * p.k + k] * p.pairs + i];
+        dot += g * wb[k];
+        dwb[k] = s * g;
+      }
+    }
+    dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) red[b][threadIdx.x >> 6] = dot;
+  }
+  __syncthreads();
+  if (threadIdx.x < p.nb)
+    dsw_part[(long long)blockIdx.x * p.nb + threadIdx.x] =
+        red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+int merge_setup(MergeK& p, const float* const* w_host, float* const* dw_host, int nb, int k, int co, int ci,
+                const int32_t* tap_host, int n_taps) {
+  UNET_REQUIRE(nb > 0 && nb <= MT_MAXB && k > 0 && k <= MT_MAXK && co > 0 && ci > 0, "merge_taps: bad sizes nb=%d k=%d", nb, k);
+  UNET_REQUIRE(n_taps > 0 && n_taps <= UNET_MAX_TAPS && tap_host && w_host, "merge_taps: bad tap table");
+  p.nb = nb; p.k = k; p.n_taps = n_taps; p.pairs = (long long)co * ci;
+  for (int b = 0; b < MT_MAXB; ++b) { p.w[b] = b < nb ? w_host[b] : nullptr; p.dw[b] = (dw_host && b < nb) ? dw_host[b] : nullptr; }
+  for (int j = 0; j < MT_MAXB * MT_MAXK; ++j) p.tap[j] = 0;
+  for (int j = 0; j < nb * k; ++j) {
+    UNET_REQUIRE(tap_host[j] >= 0 && tap_host[j] < n_taps, "merge_taps: tap index %d out of range", tap_host[j]);
+    p.tap[j] = tap_host[j];
+  }
+  for (int b = 0; b < nb; ++b) UNET_REQUIRE(p.w[b] != nullptr, "merge_taps: null branch weight");
+  UNET_REQUIRE((p.pairs + 255) / 256 < (1ll << 31), "merge_taps: too many weights");
+  return 0;
+}
+}  // namespace
+
+extern "C" int32_t unet_merge_taps_parts(int32_t co, int32_t ci) { return (int32_t)(((long long)co * ci + 255) / 256); }
+
+extern "C" int unet_merge_taps_fwd(const float* const* w_branch_host, const float* sw, int32_t n_branch, int32_t k,
+                                   int32_t co, int32_t ci, const int32_t* tap_index_host, int32_t n_taps, float* w_eff,
+                                   void* stream) {
+  MergeK p;
+  if (merge_setup(p, w_branch_host, nullptr, n_branch, k, co, ci, tap_index_host, n_taps)) return -1;
+  UNET_REQUIRE(sw && w_eff, "merge_taps_fwd: null pointer");
+  hipLaunchKernelGGL(merge_taps_fwd_kernel, dim3((unsigned)((p.pairs + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p, sw, w_eff);
+  UNET_LAUNCH_CHECK("merge_taps_fwd");
+  return 0;
+}
+
+extern "C" int unet_merge_taps_bwd(const float* const* w_branch_host, const float* sw, int32_t n_branch, int32_t k,
+                                   int32_t co, int32_t ci, const int32_t* tap_index_host, int32_t n_taps,
+                                   const float* dw_eff, float* const* dw_branch_host, float* dsw_part, void* stream) {
+  MergeK p;
+  if (merge_setup(p, w_branch_host, dw_branch_host, n_branch, k, co, ci, tap_index_host, n_taps)) return -1;
+  UNET_REQUIRE(sw && dw_eff && dw_branch_host && dsw_part, "merge_taps_bwd: null pointer");
+  for (int b = 0; b < n_branch; ++b) UNET_REQUIRE(p.dw[b] != nullptr, "merge_taps_bwd: null branch gradient");
+  hipLaunchKernelGGL(merge_taps_bwd_kernel, dim3((unsigned)((p.pairs + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p, sw, dw_eff, dsw_part);
+  UNET_LAUNCH_CHECK("merge_taps_bwd");
+  return 0;
+}

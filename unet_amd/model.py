@@ -274,15 +274,18 @@ class MultiScaleDilatedConv1d(nn.Module):
         self.scale_weights = nn.Parameter(torch.ones(self.n_scales) / self.n_scales)
         g, pairs = ops.merged_dilated_taps(kernel_size, self.dilations)
         self._geom = ops.ConvGeom(g.offs, g.phases, stride, 1, g.alg_scale)
-        self.register_buffer("_tap_index", torch.tensor([p[2] for p in pairs], dtype=torch.long), persistent=False)
+        self._tap_list = tuple(p[2] for p in pairs)
 
     def effective_weights(self) -> Tuple[Tensor, Tensor]:
         w = F.softmax(self.scale_weights.float(), dim=0)
-        ws = torch.stack([b.conv.weight for b in self.branches], dim=0).float()      # [B, Co, Ci, K]
-        ws = (ws * w[:, None, None, None]).permute(0, 3, 1, 2)                         # [B, K, Co, Ci]
-        ws = ws.reshape(-1, ws.shape[2], ws.shape[3])                                  # [(b,k), Co, Ci]
-        w_eff = torch.zeros((self._geom.n_taps,) + tuple(ws.shape[1:]), dtype=ws.dtype, device=ws.device)
-        w_eff = w_eff.index_add(0, self._tap_index, ws)
+        ws = [b.conv.weight for b in self.branches]
+        if ws[0].is_cuda:
+            w_eff = ops.MergeTapsFn.apply(w, self._tap_list, self._geom.n_taps, *ws)
+        else:  # parameter-only algebra, used by CPU-side layout checks; the conv itself has no CPU path
+            st = (torch.stack(ws, dim=0).float() * w[:, None, None, None]).permute(0, 3, 1, 2)
+            st = st.reshape(-1, st.shape[2], st.shape[3])
+            w_eff = torch.zeros((self._geom.n_taps,) + tuple(st.shape[1:]), dtype=st.dtype).index_add(
+                0, torch.tensor(self._tap_list, dtype=torch.long), st)
         b_eff = (torch.stack([b.conv.bias for b in self.branches], dim=0).float() * w[:, None]).sum(0)
         return w_eff, b_eff
 

@@ -160,6 +160,47 @@ def conv_out_len(l_in: int, k: int, stride: int, dilation: int = 1) -> int:
     return (l_in + 2 * pad - dilation * (k - 1) - 1) // stride + 1
 
 
+class MergeTapsFn(torch.autograd.Function):
+    """w_eff[T, Co, Ci] = sum over (branch, k) landing on tap t of sw[branch] * W_branch[:, :, k]
+    (the weight algebra of MultiScaleDilatedConv1d, models.py:752-759) in one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, sw, tap_index: Tuple[int, ...], n_taps: int, *branch_w):
+        lib = _lib.load()
+        nb = len(branch_w)
+        co, ci, k = branch_w[0].shape
+        ws = [w.detach().float().contiguous() for w in branch_w]
+        swf = _f32c(sw)
+        w_eff = torch.empty((n_taps, co, ci), dtype=torch.float32, device=swf.device)
+        ptrs = (C.c_void_p * nb)(*[w.data_ptr() for w in ws])
+        taps = (C.c_int32 * (nb * k))(*tap_index)
+        check(lib.unet_merge_taps_fwd(ptrs, _p(swf), nb, k, co, ci, taps, n_taps, _p(w_eff), _stream()),
+              "unet_merge_taps_fwd")
+        ctx.save_for_backward(swf, *ws)
+        ctx.meta = (tuple(tap_index), n_taps, sw.dtype, [w.dtype for w in branch_w])
+        return w_eff
+
+    @staticmethod
+    def backward(ctx, dw_eff):
+        lib = _lib.load()
+        swf, *ws = ctx.saved_tensors
+        tap_index, n_taps, sw_dtype, w_dtypes = ctx.meta
+        nb = len(ws)
+        co, ci, k = ws[0].shape
+        dw_eff = dw_eff.float().contiguous()
+        dws = [torch.empty_like(w) for w in ws]
+        parts_n = int(lib.unet_merge_taps_parts(co, ci))
+        dsw_part = torch.empty((parts_n, nb), dtype=torch.float32, device=dw_eff.device)
+        ptrs = (C.c_void_p * nb)(*[w.data_ptr() for w in ws])
+        dptrs = (C.c_void_p * nb)(*[w.data_ptr() for w in dws])
+        taps = (C.c_int32 * (nb * k))(*tap_index)
+        check(lib.unet_merge_taps_bwd(ptrs, _p(swf), nb, k, co, ci, taps, n_taps, _p(dw_eff), dptrs, _p(dsw_part),
+                                      _stream()), "unet_merge_taps_bwd")
+        dsw = torch.empty((1, nb), dtype=torch.float32, device=dw_eff.device)
+        check(lib.unet_reduce_rows(_p(dsw_part), parts_n, nb, _p(dsw), _stream()), "unet_reduce_rows")
+        return (dsw[0].to(sw_dtype), None, None) + tuple(d.to(t) for d, t in zip(dws, w_dtypes))
+
+
 # ---------------------------------------------------------------------------------------------
 # conv launchers
 # ---------------------------------------------------------------------------------------------
