@@ -520,6 +520,219 @@ __global__ __launch_bounds__(THREADS, 2) void conv_wgrad_kernel(const WgK p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// weight-gradient kernel v2 (bf16, 16-byte aligned channel runs): LDS-DMA staging of both operands into a
+// two-stage ring (the loads of position chunk i+1 land while chunk i is in the MFMAs, one barrier per chunk),
+// and up to TWO taps per block that share the output-gradient tile: for taps whose offsets differ by
+// stride*delta (delta <= 32) the input rows of the second tap are the first tap's rows shifted by delta, so one
+// (64+delta)-row input tile feeds both, the dy fragments are read from LDS once for both taps, and L2->LDS
+// traffic per FLOP drops by ~40 %.  Same split-K slab output as v1.
+// ---------------------------------------------------------------------------------------------
+constexpr int WG2_BKP = 64;                    // positions per stage
+constexpr int WG2_XROWS = WG2_BKP + 32;        // input rows per stage (max tap distance 32)
+constexpr int WG2_DY_BYTES = WG2_BKP * 256;
+constexpr int WG2_STAGE = WG2_DY_BYTES + WG2_XROWS * 256;   // 40 KiB
+
+struct Wg2K {
+  const char* x1; const char* x2; const char* dy; float* slab;
+  long long x1_ns, x2_ns, dy_ns;
+  int x1_ld, x2_ld, dy_ld;
+  int c1, c2, kt1, kttot;
+  int l_in, c_out, n;
+  int stride, up;
+  int mtiles, n_taps, n_groups, splits;
+  int mcount[2];
+  int g_tapa[UNET_MAX_TAPS];   // descriptor index of the group's first tap
+  int g_tapb[UNET_MAX_TAPS];   // ... of its second tap, or -1
+  int g_off[UNET_MAX_TAPS];    // input offset of the first tap
+  int g_delta[UNET_MAX_TAPS];  // (off_b - off_a) / stride
+  int g_phase[UNET_MAX_TAPS];
+};
+
+__global__ __launch_bounds__(THREADS, 2) void conv_wgrad2_kernel(const Wg2K p) {
+  typedef __bf16 T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int grp = wg % p.n_groups; wg /= p.n_groups;
+  const int split = wg % p.splits; wg /= p.splits;
+  const int kt = wg % p.kttot;
+  const int mt = wg / p.kttot;
+
+  const int phase = p.g_phase[grp], off0 = p.g_off[grp], delta = p.g_delta[grp];
+  const bool two = p.g_tapb[grp] >= 0;
+  const int xrows = WG2_BKP + (two ? delta : 0);
+  const int mcount = p.mcount[phase];
+  const int mchunks = (mcount + WG2_BKP - 1) / WG2_BKP;
+  const int items = p.n * mchunks;
+  const int per = (items + p.splits - 1) / p.splits;
+  const int it0 = split * per;
+  const int it1 = min(items, it0 + per);
+
+  const char* xsrc; int xld, xc, xc0; long long xns;
+  if (kt < p.kt1) { xsrc = p.x1; xld = p.x1_ld; xc = p.c1; xc0 = kt * 128; xns = p.x1_ns; }
+  else { xsrc = p.x2; xld = p.x2_ld; xc = p.c2; xc0 = (kt - p.kt1) * 128; xns = p.x2_ns; }
+  const int co0 = mt * 128;
+
+  f32x4 acc0[4][4], acc1[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { acc0[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  // ---- staging: buffer_load ... lds.  One descriptor per window (base = first row of the window, records =
+  // the window's bytes), so rows before / after the window and channel runs past the tensor fail the hardware
+  // range check and arrive in LDS as zeros; the per-lane part of every offset is loop invariant. -----------
+  constexpr unsigned OOB = 0x80000000u;
+  const int rl = lane >> 4, pc = lane & 15;   // row within a 4-row piece, physical 16-byte chunk
+  unsigned dy_voff[WG2_BKP / 16], x_voff[WG2_XROWS / 16];
+#pragma unroll
+  for (int i = 0; i < WG2_BKP / 16; ++i) {
+    const int row = (wave * (WG2_BKP / 16) + i) * 4 + rl;
+    const int e0 = co0 + (swz_t(row, pc) << 3);
+    dy_voff[i] = e0 < p.c_out ? (unsigned)((p.up * row * p.dy_ld + e0) * 2) : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < WG2_XROWS / 16; ++i) {
+    const int row = (wave + i * (THREADS / 64)) * 4 + rl;
+    const int e0 = xc0 + (swz_t(row, pc) << 3);
+    x_voff[i] = (e0 < xc && row < xrows) ? (unsigned)((p.stride * row * xld + e0) * 2) : OOB;
+  }
+  const unsigned dy_win_bytes = (unsigned)(((p.up * (mcount - 1) + phase) * p.dy_ld + p.c_out) * 2);
+  const unsigned x_win_bytes = (unsigned)(((p.l_in - 1) * xld + xc) * 2);
+  int cur_n = it0 / mchunks, cur_mc = it0 - cur_n * mchunks;     // (window, chunk) of the NEXT stage to issue
+
+  auto issue = [&](int buf) {
+    const auto dsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.dy + ((long long)cur_n * p.dy_ns + (long long)phase * p.dy_ld) * 2), 0, dy_win_bytes, 0x00020000);
+    const auto xsr = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + (long long)cur_n * xns * 2), 0, x_win_bytes, 0x00020000);
+    const int mb = cur_mc * WG2_BKP;
+    const unsigned dy_io = (unsigned)(p.up * mb * p.dy_ld * 2);
+    const unsigned x_io = (unsigned)((p.stride * mb + off0) * xld * 2);   // may be "negative": wraps past the range
+    char* sdy = smem + buf * WG2_STAGE;
+    char* sx = sdy + WG2_DY_BYTES;
+#pragma unroll
+    for (int i = 0; i < WG2_BKP / 16; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dsrc, (__attribute__((address_space(3))) void*)(sdy + (wave * (WG2_BKP / 16) + i) * 1024),
+                                               16, dy_voff[i] + dy_io, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WG2_XROWS / 16; ++i)
+      if ((wave + i * (THREADS / 64)) * 4 < xrows)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsr, (__attribute__((address_space(3))) void*)(sx + (wave + i * (THREADS / 64)) * 1024),
+                                                 16, x_voff[i] + x_io, 0, 0, 0);
+    if (++cur_mc == mchunks) { cur_mc = 0; ++cur_n; }
+  };
+
+  // ---- per-lane LDS read addresses (loop invariant; stage and k-step offsets are immediates) ----------------
+  const int q = l15 >> 2, pp = l15 & 3;
+  int a_addr[2][4], b_addr[2][4], c_addr[2][4];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int row = lq * 8 + half * 4 + q;
+    const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+    const int rowd = row + delta;
+    const int swd = ((rowd & 3) << 2) | ((rowd >> 2) & 3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a_addr[half][i] = row * 256 + ((((wm * 64 + i * 16) >> 3) + (pp >> 1)) ^ sw) * 16 + 8 * (pp & 1);
+      b_addr[half][i] = WG2_DY_BYTES + row * 256 + ((((wn * 64 + i * 16) >> 3) + (pp >> 1)) ^ sw) * 16 + 8 * (pp & 1);
+      c_addr[half][i] = WG2_DY_BYTES + rowd * 256 + ((((wn * 64 + i * 16) >> 3) + (pp >> 1)) ^ swd) * 16 + 8 * (pp & 1);
+    }
+  }
+  auto tr_read = [&](int addr) -> bf16x4 {
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + addr));
+    return __builtin_bit_cast(bf16x4, v);
+  };
+
+  auto compute = [&](int stage_off) {
+#pragma unroll
+    for (int ks = 0; ks < WG2_BKP / 32; ++ks) {
+      const int o = stage_off + ks * 32 * 256;
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          bf16x4 vb = tr_read(a_addr[half][mi] + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[mi][half * 4 + e] = vb[e];
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          bf16x4 vb = tr_read(b_addr[half][ni] + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[ni][half * 4 + e] = vb[e];
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc0[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc0[mi][ni], 0, 0, 0);
+      if (two) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            bf16x4 vb = tr_read(c_addr[half][ni] + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[ni][half * 4 + e] = vb[e];
+          }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc1[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc1[mi][ni], 0, 0, 0);
+      }
+    }
+  };
+
+  // two-stage ring, one barrier per stage.  The LDS read addresses themselves hop between the stages
+  // (+/- WG2_STAGE once per stage) so that the k-step offsets inside compute() stay immediates.
+  if (it0 < it1) {
+    issue(0);
+    int hop = WG2_STAGE, nbuf = 1;
+    for (int it = it0; it < it1; ++it) {
+      __syncthreads();   // this stage has landed (vmcnt(0) + barrier); every wave is done reading the other one
+      if (it + 1 < it1) issue(nbuf);
+      compute(0);
+#pragma unroll
+      for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a_addr[half][i] += hop; b_addr[half][i] += hop; c_addr[half][i] += hop; }
+      hop = -hop;
+      nbuf ^= 1;
+    }
+  }
+
+  // ---- store the fp32 slab tiles -------------------------------------------------------------
+  const int ctot = p.c1 + p.c2;
+  const int ci_off = (kt < p.kt1 ? 0 : p.c1);
+  auto store = [&](const f32x4 (&acc)[4][4], int tap) {
+    float* slab = p.slab + ((long long)split * p.n_taps + tap) * p.c_out * ctot;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int cl = xc0 + wn * 64 + ni * 16 + l15;  // channel within its source
+      if (cl >= xc) continue;
+      const int ci = ci_off + cl;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + wm * 64 + mi * 16 + lq * 4 + r;
+          if (co < p.c_out) slab[(long long)co * ctot + ci] = acc[mi][ni][r];
+        }
+      }
+    }
+  };
+  store(acc0, p.g_tapa[grp]);
+  if (two) store(acc1, p.g_tapb[grp]);
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, float* out, long long count, int splits) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
     float s = 0.f;
@@ -728,10 +941,84 @@ int wgrad_splits(const UnetConvDesc* d, const Phases& ph) {
 }
 }  // namespace
 
+namespace {
+// groups of <= 2 taps that can share one input tile: same phase, same (offset mod stride), distance <= 32 rows
+struct WgGroups { int n; int tapa[UNET_MAX_TAPS], tapb[UNET_MAX_TAPS], off[UNET_MAX_TAPS], delta[UNET_MAX_TAPS], phase[UNET_MAX_TAPS]; };
+
+void wgrad_groups(const UnetConvDesc* d, WgGroups* g) {
+  int order[UNET_MAX_TAPS];
+  for (int j = 0; j < d->n_taps; ++j) order[j] = j;
+  auto cls = [&](int j) { return ((d->tap_off[j] % d->stride) + d->stride) % d->stride; };
+  auto less = [&](int a, int b) {
+    if (d->tap_phase[a] != d->tap_phase[b]) return d->tap_phase[a] < d->tap_phase[b];
+    if (cls(a) != cls(b)) return cls(a) < cls(b);
+    return d->tap_off[a] < d->tap_off[b];
+  };
+  for (int i = 1; i < d->n_taps; ++i)
+    for (int k = i; k > 0 && less(order[k], order[k - 1]); --k) { int t = order[k]; order[k] = order[k - 1]; order[k - 1] = t; }
+  g->n = 0;
+  for (int i = 0; i < d->n_taps;) {
+    const int a = order[i];
+    int b = -1;
+    if (i + 1 < d->n_taps) {
+      const int c = order[i + 1];
+      if (d->tap_phase[c] == d->tap_phase[a] && cls(c) == cls(a) && (d->tap_off[c] - d->tap_off[a]) / d->stride <= 32) b = c;
+    }
+    g->tapa[g->n] = a; g->tapb[g->n] = b; g->off[g->n] = d->tap_off[a]; g->phase[g->n] = d->tap_phase[a];
+    g->delta[g->n] = b >= 0 ? (d->tap_off[b] - d->tap_off[a]) / d->stride : 0;
+    ++g->n;
+    i += b >= 0 ? 2 : 1;
+  }
+}
+
+bool wgrad2_ok(const UnetConvDesc* d, const void* x1, const void* x2, const void* dy) {
+  if (d->dtype != UNET_BF16) return false;
+  const char* env = getenv("UNET_WGRAD_V1");
+  if (env && atoi(env) == 1) return false;
+  if (d->c1 % 8 || d->c2 % 8 || d->c_out % 8) return false;
+  if (!vec_ok(x1, d->x1_ld, d->x1_ns, 2) || !vec_ok(dy, d->y_ld, d->y_ns, 2)) return false;
+  if (d->c2 > 0 && !vec_ok(x2, d->x2_ld, d->x2_ns, 2)) return false;
+  // buffer descriptors cover one window: offsets must stay below 2^31 so that "negative" rows wrap out of range
+  const long long lim = 1ll << 30;
+  if ((long long)d->l_in * d->x1_ld * 2 >= lim || (long long)d->l_out * d->y_ld * 2 >= lim) return false;
+  if (d->c2 > 0 && (long long)d->l_in * d->x2_ld * 2 >= lim) return false;
+  return true;
+}
+
+int wgrad2_splits(const UnetConvDesc* d, const Phases& ph, int groups) {
+  // Split-K factor from a small cost model: rounds of 512 resident blocks (2 per CU) x steps per block, plus the
+  // HBM round trip of the fp32 slabs (written once, read once by the reducer).  Few, long blocks keep the slab
+  // traffic below the operand traffic; the split count is chosen so that the grid fills whole rounds.
+  const int kt = cdiv(d->c1, 128) + (d->c2 > 0 ? cdiv(d->c2, 128) : 0);
+  const long long tiles = (long long)groups * cdiv(d->c_out, BM) * kt;
+  int mc = ph.mcount[0] > ph.mcount[1] ? ph.mcount[0] : ph.mcount[1];
+  const long long items = (long long)d->n * cdiv(mc, WG2_BKP);
+  const double t_step = 0.45 * (double)d->n_taps / groups;                       // us, ~32 MFMAs per wave and tap
+  const double slab_mb = (double)d->n_taps * d->c_out * (d->c1 + d->c2) * 4.0 / 1e6;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= 64 && s <= items; ++s) {
+    const double rounds = (double)((tiles * s + 511) / 512);
+    const double steps = (double)((items + s - 1) / s);
+    const double cost = rounds * (steps * t_step + 3.0) + 2.0 * s * slab_mb / 4.0;   // 4 MB/us ~ 4 TB/s
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  return best;
+}
+}  // namespace
+
 extern "C" size_t unet_conv1d_wgrad_workspace_bytes(const UnetConvDesc* d) {
   Phases ph;
-  if (!d || analyse(d, &ph)) return 0;
-  return (size_t)wgrad_splits(d, ph) * d->n_taps * d->c_out * (d->c1 + d->c2) * sizeof(float);
+  if (!d || analyse(d, &ph) || d->n_taps <= 0) return 0;
+  // the kernel (v1 / v2) is chosen at call time from pointer alignment: size for the larger slab count
+  int s = wgrad_splits(d, ph);
+  if (d->dtype == UNET_BF16) {
+    WgGroups g;
+    wgrad_groups(d, &g);
+    const int s2 = wgrad2_splits(d, ph, g.n);
+    if (s2 > s) s = s2;
+  }
+  return (size_t)s * d->n_taps * d->c_out * (d->c1 + d->c2) * sizeof(float);
 }
 
 extern "C" int unet_conv1d_wgrad(const UnetConvDesc* d, const void* x1, const void* x2, const void* dy,
@@ -741,6 +1028,44 @@ extern "C" int unet_conv1d_wgrad(const UnetConvDesc* d, const void* x1, const vo
   if (analyse(d, &ph)) return -1;
   UNET_REQUIRE(d->n_taps > 0, "conv_wgrad: no taps");
   UNET_REQUIRE(d->c2 == 0 || x2, "conv_wgrad: c2>0 but x2 is null");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long count = (long long)d->n_taps * d->c_out * (d->c1 + d->c2);
+  if (wgrad2_ok(d, x1, x2, dy)) {
+    WgGroups g;
+    wgrad_groups(d, &g);
+    const int splits = wgrad2_splits(d, ph, g.n);
+    const size_t need = (size_t)splits * count * sizeof(float);
+    UNET_REQUIRE(workspace && ws_bytes >= need, "conv_wgrad: workspace %zu bytes < %zu needed", ws_bytes, need);
+    Wg2K k;
+    k.x1 = static_cast<const char*>(x1); k.x2 = static_cast<const char*>(x2); k.dy = static_cast<const char*>(dy);
+    k.slab = static_cast<float*>(workspace);
+    k.x1_ns = d->x1_ns; k.x2_ns = d->x2_ns; k.dy_ns = d->y_ns;
+    k.x1_ld = d->x1_ld; k.x2_ld = d->x2_ld; k.dy_ld = d->y_ld;
+    k.c1 = d->c1; k.c2 = d->c2; k.kt1 = cdiv(d->c1, 128); k.kttot = k.kt1 + (d->c2 > 0 ? cdiv(d->c2, 128) : 0);
+    k.l_in = d->l_in; k.c_out = d->c_out; k.n = d->n; k.stride = d->stride; k.up = d->up;
+    k.mtiles = cdiv(d->c_out, BM); k.n_taps = d->n_taps; k.n_groups = g.n; k.splits = splits;
+    k.mcount[0] = ph.mcount[0]; k.mcount[1] = ph.mcount[1];
+    for (int j = 0; j < UNET_MAX_TAPS; ++j) {
+      const bool v = j < g.n;
+      k.g_tapa[j] = v ? g.tapa[j] : 0; k.g_tapb[j] = v ? g.tapb[j] : -1; k.g_off[j] = v ? g.off[j] : 0;
+      k.g_delta[j] = v ? g.delta[j] : 0; k.g_phase[j] = v ? g.phase[j] : 0;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad2_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG2_STAGE);
+      UNET_REQUIRE(e == hipSuccess, "conv_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      attr_set = true;
+    }
+    const long long blocks = (long long)k.mtiles * k.kttot * splits * g.n;
+    UNET_REQUIRE(blocks < (1ll << 31), "conv_wgrad: grid too large");
+    hipLaunchKernelGGL(conv_wgrad2_kernel, dim3((unsigned)blocks), dim3(THREADS), 2 * WG2_STAGE, st, k);
+    UNET_LAUNCH_CHECK("conv_wgrad2");
+    int rb = (int)((count + 255) / 256 > 4096 ? 4096 : (count + 255) / 256);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, st, k.slab, dw, count, splits);
+    UNET_LAUNCH_CHECK("slab_reduce");
+    return 0;
+  }
   const int splits = wgrad_splits(d, ph);
   const size_t need = (size_t)splits * d->n_taps * d->c_out * (d->c1 + d->c2) * sizeof(float);
   UNET_REQUIRE(workspace && ws_bytes >= need, "conv_wgrad: workspace %zu bytes < %zu needed", ws_bytes, need);
@@ -763,11 +1088,9 @@ extern "C" int unet_conv1d_wgrad(const UnetConvDesc* d, const void* x1, const vo
   }
   const long long blocks = (long long)k.mtiles * k.kttot * splits * d->n_taps;
   UNET_REQUIRE(blocks < (1ll << 31), "conv_wgrad: grid too large");
-  hipStream_t st = static_cast<hipStream_t>(stream);
   if (d->dtype == UNET_F32) hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3((unsigned)blocks), dim3(THREADS), 0, st, k);
   else hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3((unsigned)blocks), dim3(THREADS), 0, st, k);
   UNET_LAUNCH_CHECK("conv_wgrad");
-  const long long count = (long long)d->n_taps * d->c_out * (d->c1 + d->c2);
   int rb = (int)((count + 255) / 256 > 4096 ? 4096 : (count + 255) / 256);
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, st, k.slab, dw, count, splits);
   UNET_LAUNCH_CHECK("slab_reduce");
