@@ -278,6 +278,237 @@ __global__ __launch_bounds__(THREADS, 2) void conv_fwd_kernel(const ConvK p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward / data-grad kernel v2 (bf16, 16-byte aligned channel runs).  Same tiling, LDS images and epilogue as
+// conv_fwd_kernel; what changes is the instruction stream around the MFMAs, which in v1 carried ~2 VALU and
+// ~2 SALU instructions per MFMA (rocprofv3: SQ_INSTS_VALU / SQ_INSTS_VALU_MFMA_MOPS) and was issue-bound:
+//   * both operands are staged with buffer_load ... lds: the per-lane part of every address is computed once
+//     per block (rows of the halo tile never change), rows outside the window fail the descriptor's range
+//     check and arrive as zeros, the weight tile needs no per-lane address at all (instruction offsets);
+//   * LDS fragment addresses: A per block, B once per tap (row swizzle of the tap's first row), all
+//     fragment / k-step / buffer offsets are instruction immediates (step loop unrolled by two);
+//   * step bookkeeping is incremental scalar arithmetic (no integer divisions in the loop).
+// ---------------------------------------------------------------------------------------------
+constexpr int F2_MAXP = 12;   // x-tile pieces (8 rows of 128 B) per wave: halo tiles up to 384 rows
+
+template <int BN>
+__device__ __forceinline__ void conv_fwd2_body(const ConvK& p) {
+  typedef __bf16 T;
+  constexpr int NI = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XB = 2 * WTILE_BYTES;   // byte offset of the input tile buffers
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  // ---- which tile -------------------------------------------------------------------------
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int ppw = p.ptiles[0] + p.ptiles[1];
+  const int per_mt = p.n * ppw;
+  const int mt = wg / per_mt;
+  int rem = wg - mt * per_mt;
+  const int n = rem / ppw;
+  int pt = rem - n * ppw;
+  int phase = 0;
+  if (pt >= p.ptiles[0]) { phase = 1; pt -= p.ptiles[0]; }
+  const int m0 = pt * BN;
+  const int tb = p.pbeg[phase];
+  const int nt = p.pbeg[phase + 1] - tb;
+  const int rows0 = p.seg_rows[phase][0], rows1 = p.seg_rows[phase][1];
+  const int R = rows0 + rows1;
+  const int g0a = p.stride * (m0 + p.seg_q0[phase][0]);
+  const int g0b = p.stride * (m0 + p.seg_q0[phase][1]) + 1;
+
+  f32x4 acc[4][NI];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging ------------------------------------------------------------------------------
+  constexpr unsigned OOB = 0x80000000u;
+  const auto wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 0x7fffffff, 0x00020000);
+  const unsigned w_voff = (unsigned)(wave * 4096 + lane * 16);
+  const unsigned w_jstride = (unsigned)p.mtiles * p.kctot * WTILE_BYTES;
+  const unsigned w_base = ((unsigned)tb * p.mtiles + mt) * p.kctot * WTILE_BYTES;   // tile (tap tb, mt, kc 0)
+
+  auto issue_w = [&](unsigned tile_off, int buf) {   // 16 KiB tile: 4 wave-instructions of 1 KiB per wave
+    auto dst = (__attribute__((address_space(3))) void*)(smem + buf * WTILE_BYTES + wave * 4096);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, dst, 16, w_voff, tile_off, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, dst, 16, w_voff, tile_off, 1024, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, dst, 16, w_voff, tile_off, 2048, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, dst, 16, w_voff, tile_off, 3072, 0);
+  };
+
+  // input tile: piece pc (8 rows) of this wave's k-th slot is pc = wave + 4k.  x_voff[k] = byte offset of the
+  // lane's 16-byte chunk inside the window for K-chunk 0 of the current source (rows fixed per block).
+  unsigned x_voff[F2_MAXP];
+  const int rl = lane >> 3, cp = lane & 7;
+  const int pieces = (R + 7) >> 3;
+  auto setup_x = [&](int ld, int chunks_valid) {   // chunks_valid: 16-byte chunks of this K-chunk that exist (1..8)
+#pragma unroll
+    for (int k = 0; k < F2_MAXP; ++k) {
+      const int i = (wave + 4 * k) * 8 + rl;
+      const int c = swz(i, cp);
+      const int g = i < rows0 ? g0a + p.stride * i : g0b + p.stride * (i - rows0);
+      const bool ok = i < R && g >= 0 && g < p.l_in && c < chunks_valid;
+      x_voff[k] = ok ? (unsigned)((g * ld + c * 8) * 2) : OOB;
+    }
+  };
+  auto x_srd = [&](const char* base, long long ns, int ld, int c) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long long)n * ns * 2), 0,
+                                             (unsigned)(((p.l_in - 1) * ld + c) * 2), 0x00020000);
+  };
+  const auto srd1 = x_srd(p.x1, p.x1_ns, p.x1_ld, p.c1);
+  const auto srd2 = p.c2 > 0 ? x_srd(p.x2, p.x2_ns, p.x2_ld, p.c2) : srd1;
+  const int tail1 = (p.c1 & 63) ? ((p.c1 & 63) >> 3) : 8, tail2 = (p.c2 & 63) ? ((p.c2 & 63) >> 3) : 8;
+
+  auto issue_x = [&](int kc, int buf) {
+    // (re)derive the per-lane offsets when the source or the chunk validity changes: at most 4 times per block
+    const bool src2 = kc >= p.kc1;
+    const int kcl = src2 ? kc - p.kc1 : kc;
+    const int last = src2 ? (p.kctot - p.kc1 - 1) : (p.kc1 - 1);
+    const int tail = src2 ? tail2 : tail1;
+    if (kcl == 0 || (kcl == last && tail != 8)) setup_x(src2 ? p.x2_ld : p.x1_ld, kcl == last ? tail : 8);
+    const unsigned soff = (unsigned)(kcl * 128);
+    char* dst = smem + XB + buf * p.xbytes;
+#pragma unroll
+    for (int k = 0; k < F2_MAXP; ++k) {
+      const int pc = wave + 4 * k;
+      if (pc < pieces) {
+        if (src2) __builtin_amdgcn_raw_ptr_buffer_load_lds(srd2, (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, x_voff[k], soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(srd1, (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, x_voff[k], soff, 0, 0);
+      }
+    }
+  };
+
+  // ---- LDS fragment addresses ---------------------------------------------------------------
+  int a_addr[2][4];   // [k-step][mi]; hops between the two weight buffers (xor 16 KiB) once per step
+  {
+    const int a_sw = (l15 >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) a_addr[ks][mi] = (wm * 64 + mi * 16 + l15) * 128 + (((ks * 4 + lq) ^ a_sw) << 4);
+  }
+  const int b_row_lane = wn * (BN / 2) + l15;
+
+  auto compute = [&](int tap, int xb_off) {
+    const int row0 = p.tap_row[tap] + b_row_lane;          // fragment ni reads row0 + 16*ni: same swizzle for all ni
+    const int b_sw = (row0 >> 1) & 7;
+    const int b0 = xb_off + row0 * 128 + ((lq ^ b_sw) << 4);
+    const int b1 = b0 ^ 64;                                  // k-step 1: chunk index bit 2 flips
+    bf16x8 a[4], b[NI];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(smem + a_addr[0][mi]);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(smem + b0 + ni * 2048);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(smem + a_addr[1][mi]);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(smem + b1 + ni * 2048);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) a_addr[ks][mi] ^= WTILE_BYTES;
+  };
+
+  // ---- main loop: K-chunks (outer) x taps (inner).  The weight tile of the next step is requested right after
+  // the barrier that opens a step; the input tile of the next K-chunk is requested at the first step of a chunk
+  // when two tiles fit (xdb), otherwise it is restaged between chunks.  All chunk-level work (source switch,
+  // per-lane offsets) stays out of the inner tap loop. ---------------------------------------------------------
+  if (p.kctot > 0 && nt > 0) {
+    issue_w(w_base, 0);
+    issue_x(0, 0);
+    int wbuf = 0;
+    for (int kc = 0; kc < p.kctot; ++kc) {
+      const bool last_chunk = kc + 1 == p.kctot;
+      const int xoff = XB + (p.xdb ? (kc & 1) * p.xbytes : 0);
+      unsigned w_cur = w_base + (unsigned)kc * WTILE_BYTES;
+      // first tap of the chunk
+      __syncthreads();   // everything issued so far has landed (vmcnt(0)); previous step's reads are done
+      if (nt > 1) { w_cur += w_jstride; issue_w(w_cur, wbuf ^ 1); }
+      else if (!last_chunk) issue_w(w_base + (unsigned)(kc + 1) * WTILE_BYTES, wbuf ^ 1);
+      if (p.xdb && !last_chunk) issue_x(kc + 1, (kc + 1) & 1);
+      compute(tb, xoff);
+      wbuf ^= 1;
+      // remaining taps
+      for (int j = 1; j < nt; ++j) {
+        __syncthreads();
+        if (j + 1 < nt) { w_cur += w_jstride; issue_w(w_cur, wbuf ^ 1); }
+        else if (!last_chunk) issue_w(w_base + (unsigned)(kc + 1) * WTILE_BYTES, wbuf ^ 1);
+        compute(tb + j, xoff);
+        wbuf ^= 1;
+      }
+      if (!p.xdb && !last_chunk) {
+        __syncthreads();  // every wave is done with the input tile of this K-chunk
+        issue_x(kc + 1, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: bias, residual, activation, store (4 consecutive channels per lane) --------
+  T* ybase = reinterpret_cast<T*>(p.y) + (long long)n * p.y_ns;
+  const T* rbase = p.res ? reinterpret_cast<const T*>(p.res) + (long long)n * p.res_ns : nullptr;
+  const int mcount = p.mcount[phase];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int m = m0 + wn * (BN / 2) + ni * 16 + l15;
+    if (m >= mcount) continue;
+    const long long o = (long long)p.up * m + phase;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int co = mt * BM + wm * 64 + mi * 16 + lq * 4;
+      if (co >= p.c_out) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r];
+      const bool full = co + 4 <= p.c_out;
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (co + r < p.c_out) v[r] += p.bias[co + r];
+      }
+      if (rbase) {
+        const T* rp = rbase + o * p.res_ld + co;
+        if (full && p.res_vec) {
+          float rv[4];
+          VecIO<T, 4>::load(rp, rv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += rv[r];
+        } else {
+          for (int r = 0; r < 4; ++r)
+            if (co + r < p.c_out) v[r] += to_f32(rp[r]);
+        }
+      }
+      if (p.act != UNET_ACT_NONE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
+      }
+      T* yp = ybase + o * p.y_ld + co;
+      if (full && p.y_vec) {
+        VecIO<T, 4>::store(yp, v);
+      } else {
+        for (int r = 0; r < 4; ++r)
+          if (co + r < p.c_out) yp[r] = from_f32<T>(v[r]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_128(const ConvK p) { conv_fwd2_body<128>(p); }
+__global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_64(const ConvK p) { conv_fwd2_body<64>(p); }
+
+// ---------------------------------------------------------------------------------------------
 // weight packing:  fp32 w[tap][row][col] (strided)  ->  [tap][row tile][K chunk][128 rows][8 chunks x 16 B]
 // in the swizzled LDS image of conv_fwd_kernel.
 // ---------------------------------------------------------------------------------------------
@@ -827,6 +1058,28 @@ void tile_geom(const UnetConvDesc* d, const Phases& ph, int bn, TileGeom* tg) {
   }
 }
 
+template <int BN>
+int launch_fwd2(ConvK& k, int rmax, hipStream_t st) {
+  static bool attr_set = false;
+  const int xbytes = ((rmax + 7) / 8) * 1024;
+  k.xbytes = xbytes;
+  k.xdb = (2 * WTILE_BYTES + 2 * (size_t)xbytes <= 80 * 1024) ? 1 : 0;
+  const size_t lds = 2 * WTILE_BYTES + (size_t)xbytes * (k.xdb ? 2 : 1);
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(BN == 128 ? reinterpret_cast<const void*>(&conv_fwd2_kernel_128)
+                                                 : reinterpret_cast<const void*>(&conv_fwd2_kernel_64),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    UNET_REQUIRE(e == hipSuccess, "conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const long long blocks = (long long)k.mtiles * k.n * (k.ptiles[0] + k.ptiles[1]);
+  UNET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv: grid of %lld blocks", blocks);
+  if (BN == 128) hipLaunchKernelGGL(conv_fwd2_kernel_128, dim3((unsigned)blocks), dim3(THREADS), lds, st, k);
+  else hipLaunchKernelGGL(conv_fwd2_kernel_64, dim3((unsigned)blocks), dim3(THREADS), lds, st, k);
+  UNET_LAUNCH_CHECK("conv_fwd2");
+  return 0;
+}
+
 template <bool F32, int BN>
 int launch_fwd(ConvK& k, int rmax, hipStream_t st) {
   static bool attr_set = false;
@@ -922,6 +1175,18 @@ extern "C" int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void
   }
   for (int j = 0; j < UNET_MAX_TAPS; ++j) k.tap_row[j] = tg.tap_row[j];
   hipStream_t st = static_cast<hipStream_t>(stream);
+  {
+    // v2 (lean instruction stream, buffer LDS-DMA): bf16, aligned channel runs, halo tile within 12 pieces per wave,
+    // window and packed-weight byte offsets that fit the 32-bit buffer offsets
+    const char* env = getenv("UNET_CONV_V1");
+    const long long lim = 1ll << 30;
+    const bool v2 = !(env && atoi(env) == 1) && d->dtype == UNET_BF16 && k.x1_fast && (d->c2 == 0 || k.x2_fast) &&
+                    (tg.rmax + 7) / 8 <= 4 * F2_MAXP && (long long)d->l_in * d->x1_ld * 2 < lim &&
+                    (d->c2 == 0 || (long long)d->l_in * d->x2_ld * 2 < lim) &&
+                    (long long)d->n_taps * k.mtiles * k.kctot * WTILE_BYTES < lim &&
+                    2 * WTILE_BYTES + (size_t)((tg.rmax + 7) / 8) * 1024 <= 160 * 1024;
+    if (v2) return bn == 128 ? launch_fwd2<128>(k, tg.rmax, st) : launch_fwd2<64>(k, tg.rmax, st);
+  }
   if (d->dtype == UNET_F32) return bn == 128 ? launch_fwd<true, 128>(k, tg.rmax, st) : launch_fwd<true, 64>(k, tg.rmax, st);
   return bn == 128 ? launch_fwd<false, 128>(k, tg.rmax, st) : launch_fwd<false, 64>(k, tg.rmax, st);
 }
