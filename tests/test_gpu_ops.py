@@ -32,6 +32,10 @@ CONV_CASES = [
     (2, 128, 130, 200, 7, 2, 16),
     (1, 256, 256, 384, 7, 1, 32),
     (2, 6, 4, 37, 3, 2, 1),
+    # single-tap convs with >= 3 K-chunks: the persistent streaming kernel (ragged K tail, ragged tiles)
+    (2, 192, 256, 300, 1, 1, 1),
+    (3, 520, 136, 257, 1, 1, 1),
+    (70, 256, 128, 129, 1, 1, 1),
 ]
 
 

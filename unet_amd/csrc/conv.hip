@@ -509,6 +509,201 @@ __global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_128(const ConvK p
 __global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_64(const ConvK p) { conv_fwd2_body<64>(p); }
 
 // ---------------------------------------------------------------------------------------------
+// Streaming kernel for single-tap (1x1) convolutions: FiLM q_proj / out_proj, skip_proj, residual_conv and
+// their data gradients (models.py:492,495,605,910,3049).  These have K = Cin only (4..16 K-chunks per output
+// tile), move 2 bytes per ~C FLOPs and are HBM-latency-bound in the tap-loop kernels, whose blocks live for a
+// handful of steps and prefetch one step ahead.  Here a workgroup is PERSISTENT (one per CU): it walks its list
+// of output tiles as one continuous stream of (weight tile, input chunk) stages through a 4-deep LDS ring filled
+// by buffer_load ... lds, with counted s_waitcnt vmcnt(N) and raw s_barrier so that three stages (96 KiB per CU)
+// stay in flight across barriers, tile boundaries and epilogues.  Every wave issues exactly 8 loads per stage and
+// 16 stores per tile, which is what makes the counts exact (CDNA4 counts loads and stores on one counter).
+// ---------------------------------------------------------------------------------------------
+constexpr int ST_D = 3;                       // ring depth
+constexpr int ST_THREADS = 512;               // 8 waves: 4 (output-channel groups of 64) x 2 (position halves)
+constexpr int ST_BM = 256;                    // output channels per tile = two packed 128-row weight tiles
+constexpr int ST_SLOT = 3 * WTILE_BYTES;      // 32 KiB weights + 16 KiB input chunk (128 positions x 64 channels)
+constexpr int ST_BIAS = ST_D * ST_SLOT;       // fp32 bias of every output channel (<= 8 KiB) behind the ring
+constexpr int ST_MAXC = 2048;
+
+__global__ __launch_bounds__(ST_THREADS, 1) void conv_stream_kernel(const ConvK p, const unsigned w_bytes) {
+  typedef __bf16 T;
+  constexpr int BN = 128, NI = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+  constexpr unsigned OOB = 0x80000000u;
+
+  const int G = gridDim.x;
+  const int lb = xcd_remap(blockIdx.x, G);
+  const int ptiles = p.ptiles[0];
+  const int mt2 = (p.mtiles + 1) >> 1;          // 256-channel tiles
+  const int tiles = mt2 * p.n * ptiles;
+  const int my_tiles = lb < tiles ? (tiles - lb + G - 1) / G : 0;
+  const int kct = p.kctot;
+  const int total = my_tiles * kct;
+  const int q0 = p.seg_q0[0][0];               // input row of output position 0 (the tap offset)
+
+  // bias -> LDS once (read back per tile with ds_read: no vector-memory wait in the pipeline)
+  float* sbias = reinterpret_cast<float*>(smem + ST_BIAS);
+  for (int c = tid; c < mt2 * ST_BM; c += ST_THREADS) sbias[c] = (p.bias && c < p.c_out) ? p.bias[c] : 0.f;
+
+  // packed weights: records = the image's exact size, so the absent second half of a last, odd tile reads zeros
+  const auto wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, w_bytes, 0x00020000);
+  const unsigned w_voff = (unsigned)((wave & 3) * 4096 + lane * 16);
+  const int rl = lane >> 3, cp = lane & 7;
+  const int tail = (p.c1 & 63) ? ((p.c1 & 63) >> 3) : 8;
+  const unsigned x_win = (unsigned)(((p.l_in - 1) * p.x1_ld + p.c1) * 2);
+  const unsigned y_win = (unsigned)(((p.l_out - 1) * p.y_ld + p.c_out) * 2);
+
+  // ---- issue cursor: (tile index in my list, K-chunk) of the next stage to request ------------------
+  int i_tile = 0, i_kc = 0, i_mt = 0, i_n = 0, i_m0 = 0;
+  unsigned x_voff[2], x_voff_tail[2];
+  auto decode = [&](int it, int& mt, int& n, int& m0) {
+    const int t = lb + it * G;
+    mt = t % mt2;
+    const int r = t / mt2;
+    const int pt = r % ptiles;
+    n = r / ptiles;
+    m0 = pt * BN;
+  };
+  auto setup_issue_tile = [&]() {
+    decode(i_tile, i_mt, i_n, i_m0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = (wave + 8 * k) * 8 + rl;
+      const int c = swz(i, cp);
+      const int g = i_m0 + q0 + i;
+      const bool ok = g >= 0 && g < p.l_in;
+      x_voff[k] = ok ? (unsigned)((g * p.x1_ld + c * 8) * 2) : OOB;
+      x_voff_tail[k] = (ok && c < tail) ? x_voff[k] : OOB;
+    }
+  };
+  auto issue_slot = [&](int slot) {   // exactly 6 loads per wave
+    const auto xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x1 + (long long)i_n * p.x1_ns * 2), 0, x_win, 0x00020000);
+    // waves 0-3 fetch the 128-row tile 2*mt, waves 4-7 the tile 2*mt+1 (if it exists; else out of range -> zeros)
+    const unsigned w_off = (unsigned)((2 * i_mt + (wave >> 2)) * kct + i_kc) * WTILE_BYTES;
+    auto wdst = (__attribute__((address_space(3))) void*)(smem + slot * ST_SLOT + wave * 4096);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, wdst, 16, w_voff + w_off, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, wdst, 16, w_voff + w_off, 0, 1024, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, wdst, 16, w_voff + w_off, 0, 2048, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, wdst, 16, w_voff + w_off, 0, 3072, 0);
+    const unsigned soff = (unsigned)(i_kc * 128);
+    const bool last = i_kc == kct - 1;
+    char* xdst = smem + slot * ST_SLOT + 2 * WTILE_BYTES;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (__attribute__((address_space(3))) void*)(xdst + (wave + 8 * k) * 1024), 16,
+                                               last ? x_voff_tail[k] : x_voff[k], soff, 0, 0);
+    if (++i_kc == kct) { i_kc = 0; ++i_tile; if (i_tile < my_tiles) setup_issue_tile(); }
+  };
+
+  // ---- LDS fragment addresses (slot 0); the tap row is 0 for a single tap ------------------------------
+  int a_addr[2][4], b_addr[2];
+  {
+    const int a_sw = (l15 >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) a_addr[ks][mi] = (wm * 64 + mi * 16 + l15) * 128 + (((ks * 4 + lq) ^ a_sw) << 4);
+    const int row0 = wn * (BN / 2) + l15;
+    const int b_sw = (row0 >> 1) & 7;
+    b_addr[0] = 2 * WTILE_BYTES + row0 * 128 + ((lq ^ b_sw) << 4);
+    b_addr[1] = b_addr[0] ^ 64;
+  }
+
+  f32x4 acc[4][NI];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
+
+  if (total > 0) {
+    setup_issue_tile();
+    __syncthreads();                      // bias in LDS
+#pragma unroll
+    for (int s = 0; s < ST_D - 1; ++s)
+      if (s < total) issue_slot(s);
+
+    // The K loop is skewed by half a stage: the second 32-channel half of stage g-1 (fragments already in
+    // registers) multiplies while the first half of stage g is read from LDS, and vice versa, so no LDS read
+    // latency is exposed between barriers.  A tile's epilogue therefore runs one step after its last stage.
+    auto epilogue = [&](int tile) {
+      // + bias, bf16, 16 buffer stores per wave (rows / channels outside the tensor are dropped by the range
+      // check, so the store COUNT is the same for every wave and tile)
+      int mt, n, m0;
+      decode(tile, mt, n, m0);
+      const auto ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)n * p.y_ns * 2), 0, y_win, 0x00020000);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int m = m0 + wn * (BN / 2) + ni * 16 + l15;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const int co = mt * ST_BM + wm * 64 + mi * 16 + lq * 4;
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + co);
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (__bf16)(acc[mi][ni][r] + bv[r]);
+          const unsigned voff = (m < p.l_out && co < p.c_out) ? (unsigned)((m * p.y_ld + co) * 2) : OOB;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ysrd, voff, 0, 0);
+        }
+      }
+      zero_acc();
+    };
+    auto mma = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[NI]) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    };
+
+    int c_tile = 0, c_kc = 0, slot = 0, after = 0;
+    bf16x8 a0[4], b0[NI], a1[4], b1[NI];
+    for (int g = 0; g < total; ++g) {
+      // stage g must have landed; the stage requested after it (6 loads per wave) may stay in flight -- plus, for
+      // the two steps after a tile epilogue, that tile's 16 stores, which are younger than the stages that were in
+      // flight when they were issued (loads and stores share the counter and retire in order)
+      const int rem = total - 1 - g;
+      if (rem >= 1) {
+        if (after > 0) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (after > 0) --after;
+      __builtin_amdgcn_s_barrier();       // every wave's part of stage g is in LDS; stage g-1's buffer is free
+      if (g + ST_D - 1 < total) issue_slot(slot == 0 ? ST_D - 1 : slot - 1);
+
+      const int so = slot * ST_SLOT;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) a0[mi] = *reinterpret_cast<const bf16x8*>(smem + a_addr[0][mi] + so);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b0[ni] = *reinterpret_cast<const bf16x8*>(smem + b_addr[0] + so + ni * 2048);
+      if (g > 0) {
+        mma(a1, b1);                      // second half of stage g-1
+        if (c_kc == 0) {                  // ... which closed a tile
+          epilogue(c_tile - 1);
+          after = 2;
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) a1[mi] = *reinterpret_cast<const bf16x8*>(smem + a_addr[1][mi] + so);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b1[ni] = *reinterpret_cast<const bf16x8*>(smem + b_addr[1] + so + ni * 2048);
+      mma(a0, b0);
+      slot = slot + 1 == ST_D ? 0 : slot + 1;
+      if (++c_kc == kct) { c_kc = 0; ++c_tile; }
+    }
+    mma(a1, b1);
+    epilogue(c_tile - 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight packing:  fp32 w[tap][row][col] (strided)  ->  [tap][row tile][K chunk][128 rows][8 chunks x 16 B]
 // in the swizzled LDS image of conv_fwd_kernel.
 // ---------------------------------------------------------------------------------------------
@@ -1080,6 +1275,31 @@ int launch_fwd2(ConvK& k, int rmax, hipStream_t st) {
   return 0;
 }
 
+int launch_stream(ConvK& k, hipStream_t st) {
+  static bool attr_set = false;
+  static int n_cu = 0;
+  const int mt2 = (k.mtiles + 1) / 2;
+  const size_t lds = ST_BIAS + (size_t)mt2 * ST_BM * sizeof(float);
+  const unsigned w_bytes = (unsigned)((size_t)k.mtiles * k.kctot * WTILE_BYTES);
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stream_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    UNET_REQUIRE(e == hipSuccess, "conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    int dev = 0;
+    e = hipGetDevice(&dev);
+    UNET_REQUIRE(e == hipSuccess, "conv: hipGetDevice failed: %s", hipGetErrorString(e));
+    e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    UNET_REQUIRE(e == hipSuccess && n_cu > 0, "conv: cannot read the CU count");
+    attr_set = true;
+  }
+  const long long tiles = (long long)mt2 * k.n * k.ptiles[0];
+  UNET_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv: %lld tiles", tiles);
+  const unsigned blocks = (unsigned)(tiles < n_cu ? tiles : n_cu);   // one persistent workgroup per CU
+  hipLaunchKernelGGL(conv_stream_kernel, dim3(blocks), dim3(ST_THREADS), lds, st, k, w_bytes);
+  UNET_LAUNCH_CHECK("conv_stream");
+  return 0;
+}
+
 template <bool F32, int BN>
 int launch_fwd(ConvK& k, int rmax, hipStream_t st) {
   static bool attr_set = false;
@@ -1185,6 +1405,12 @@ extern "C" int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void
                     (d->c2 == 0 || (long long)d->l_in * d->x2_ld * 2 < lim) &&
                     (long long)d->n_taps * k.mtiles * k.kctot * WTILE_BYTES < lim &&
                     2 * WTILE_BYTES + (size_t)((tg.rmax + 7) / 8) * 1024 <= 160 * 1024;
+    // single-tap convs with enough K-chunks: the persistent streaming kernel (deep LDS ring)
+    const char* envs = getenv("UNET_CONV_NOSTREAM");
+    const bool stream = v2 && !(envs && atoi(envs) == 1) && d->n_taps == 1 && d->up == 1 && d->stride == 1 && d->c2 == 0 &&
+                        k.kctot >= 3 && d->c_out <= ST_MAXC && d->c_out % 4 == 0 && !res && d->act == UNET_ACT_NONE &&
+                        k.y_vec && bn == 128 && (long long)d->l_out * d->y_ld * 2 < lim;
+    if (stream) return launch_stream(k, st);
     if (v2) return bn == 128 ? launch_fwd2<128>(k, tg.rmax, st) : launch_fwd2<64>(k, tg.rmax, st);
   }
   if (d->dtype == UNET_F32) return bn == 128 ? launch_fwd<true, 128>(k, tg.rmax, st) : launch_fwd<true, 64>(k, tg.rmax, st);
