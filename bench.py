@@ -13,8 +13,10 @@ cross_attn_gated FiLM; 41,966,772 parameters), synthetic N(0,1) windows of 32 ch
 i.e. everything the reference's train_epoch does per batch (train.py:1395-1560).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the dominant kernel (implicit-GEMM conv forward/data-grad on bf16 MFMA), timed
-                  live with HIP events around every launch of the timed region
+  roofline     -- the dominant kernel (conv_fwd2_kernel: implicit-GEMM conv forward/data-grad on bf16
+                  MFMA), timed live with HIP events around every launch (include/unet_hip.h
+                  unet_conv1d_last_variant attributes each launch to its kernel); "traffic" = HBM bytes
+                  per launch from the committed rocprofv3 --pmc passes (scripts/pmc_traffic.sh)
   cpu_baseline -- the CPU oracle (oracle/condunet_oracle.py, a port of the reference's algorithm
                   in torch fp32) timed on this box's host cores on a bounded sample
 """
@@ -39,6 +41,13 @@ T = 4096
 CROP = (500, 4500)
 GFLOP_PER_WINDOW_FWD = 122.339       # algorithmic conv FLOPs, config B
 BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+KERNEL_DESCR = {
+    "conv_fwd2_kernel": "conv_fwd2_kernel_128 (bf16 implicit-GEMM tap-list conv, forward and data-grad launches)",
+    "conv_stream_kernel": "conv_stream_kernel (bf16 single-tap conv, persistent 256x128 tiles)",
+    "conv_wgrad2_kernel": "conv_wgrad2_kernel (bf16 weight-grad, two taps per block, split-K slabs)",
+    "conv_fwd_kernel": "conv_fwd_kernel (generic / fp32 implicit-GEMM conv)",
+    "conv_wgrad_kernel": "conv_wgrad_kernel (generic / fp32 weight-grad)",
+}
 
 
 def parse():
@@ -212,10 +221,23 @@ def main():
             a[2] += 1
         kern = {k: {"launches": v[2], "avg_us": 1e6 * v[1] / v[2], "tflops_algorithmic": v[0] / v[1] / 1e12,
                     "ms_per_step": 1e3 * v[1] / prof_steps} for k, v in agg.items()}
-        dom = agg["conv_fwd"]
-        out["roofline"] = {"bound": "mfma", "kernel": "conv_fwd_kernel<bf16> (implicit-GEMM conv forward + data-grad)",
+        # dominant kernel = the conv kernel with the largest share of the step (conv_fwd2_kernel: tiled
+        # implicit-GEMM forward / data-grad); its HBM traffic per launch comes from the committed PMC passes
+        dom_name = max(agg, key=lambda k: agg[k][1])
+        dom = agg[dom_name]
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath) and B == 64 and args.dtype == "bf16":
+            tk = json.load(open(tpath))["kernels"]
+            hit = [v for k, v in tk.items() if k.startswith(dom_name)]
+            if hit:
+                traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit)
+                traffic_src = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this step, FETCH_SIZE doubled for gfx950)"
+        out["roofline"] = {"bound": "mfma", "kernel": KERNEL_DESCR.get(dom_name, dom_name),
                            "achieved": dom[0] / dom[1] / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": dom[0] / dom[1] / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                           "frac": dom[0] / dom[1] / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                           "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                           "flops_per_launch_algorithmic": dom[0] / dom[2],
                            "avg_launch_us": 1e6 * dom[1] / dom[2], "launches": dom[2], "timing": timing_mode}
         out["kernels"] = kern
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

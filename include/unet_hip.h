@@ -82,6 +82,17 @@ int unet_conv1d_pack(int32_t dtype, const float* w, int64_t tap_stride, int64_t 
 int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void* x2, const void* w_packed,
                     const float* bias, const void* res, void* y, void* stream);
 
+/* Which kernel the calling thread's most recent unet_conv1d_fwd / unet_conv1d_wgrad launch used.  No
+ * counterpart in the reference (cuDNN picks its algorithm internally, models.py convs); bench.py uses it
+ * to attribute live launch timings to the kernel named in its roofline object. */
+enum { UNET_VARIANT_NONE = 0,
+       UNET_VARIANT_FWD_GENERIC = 1,   /* conv_fwd_kernel: fp32 (exact 16x16x4 MFMA) or unaligned bf16 */
+       UNET_VARIANT_FWD_TILED = 2,     /* conv_fwd2_kernel_128/_64: bf16, buffer LDS-DMA, halo tile + tap loop */
+       UNET_VARIANT_FWD_STREAM = 3,    /* conv_stream_kernel: bf16 single-tap convs, persistent, 256x128 tiles */
+       UNET_VARIANT_WGRAD_GENERIC = 11,/* conv_wgrad_kernel */
+       UNET_VARIANT_WGRAD_PAIRED = 12  /* conv_wgrad2_kernel: bf16, two taps per block, LDS-DMA ring */ };
+int unet_conv1d_last_variant(void);
+
 /* Weight gradient:  dw[j][co][ci] (fp32, contiguous, ci over c1+c2) =
  *   sum_n sum_m dy[n, up*m+phase_j, co] * x[n, stride*m+off_j, ci]
  * d describes the FORWARD conv (dy has d->l_out rows, d->c_out channels, pitch y_ld/y_ns).

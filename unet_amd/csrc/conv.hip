@@ -512,11 +512,13 @@ __global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_64(const ConvK p)
 // Streaming kernel for single-tap (1x1) convolutions: FiLM q_proj / out_proj, skip_proj, residual_conv and
 // their data gradients (models.py:492,495,605,910,3049).  These have K = Cin only (4..16 K-chunks per output
 // tile), move 2 bytes per ~C FLOPs and are HBM-latency-bound in the tap-loop kernels, whose blocks live for a
-// handful of steps and prefetch one step ahead.  Here a workgroup is PERSISTENT (one per CU): it walks its list
-// of output tiles as one continuous stream of (weight tile, input chunk) stages through a 4-deep LDS ring filled
-// by buffer_load ... lds, with counted s_waitcnt vmcnt(N) and raw s_barrier so that three stages (96 KiB per CU)
-// stay in flight across barriers, tile boundaries and epilogues.  Every wave issues exactly 8 loads per stage and
-// 16 stores per tile, which is what makes the counts exact (CDNA4 counts loads and stores on one counter).
+// handful of steps and prefetch one step ahead.  Here a workgroup is PERSISTENT (one per CU, 8 waves): it walks
+// its list of 256(co) x 128(pos) output tiles as one continuous stream of (two weight tiles, input chunk) stages
+// through a 3-deep LDS ring filled by buffer_load ... lds, with counted s_waitcnt vmcnt(N) and raw s_barrier so
+// that two stages (96 KiB per CU) stay in flight across barriers, tile boundaries and epilogues.  Every wave
+// issues exactly 6 loads per stage and 16 stores per tile, which is what makes the counts exact (CDNA4 counts
+// loads and stores on one counter).  The 256-channel tile halves the input bytes streamed per FLOP, which is
+// what bounds these convs (L2 -> LDS bandwidth), relative to the 128 x 128 tile of the tap-loop kernel.
 // ---------------------------------------------------------------------------------------------
 constexpr int ST_D = 3;                       // ring depth
 constexpr int ST_THREADS = 512;               // 8 waves: 4 (output-channel groups of 64) x 2 (position halves)
@@ -1351,6 +1353,11 @@ extern "C" int unet_conv1d_pack(int32_t dtype, const float* w, int64_t tap_strid
   return 0;
 }
 
+namespace { thread_local int g_last_variant = 0; }
+
+// which kernel the calling thread's most recent conv launch used (profiling aid; see include/unet_hip.h)
+extern "C" int unet_conv1d_last_variant(void) { return g_last_variant; }
+
 extern "C" int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void* x2, const void* w_packed,
                                const float* bias, const void* res, void* y, void* stream) {
   UNET_REQUIRE(d && x1 && w_packed && y, "conv_fwd: null pointer");
@@ -1410,9 +1417,13 @@ extern "C" int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void
     const bool stream = v2 && !(envs && atoi(envs) == 1) && d->n_taps == 1 && d->up == 1 && d->stride == 1 && d->c2 == 0 &&
                         k.kctot >= 3 && d->c_out <= ST_MAXC && d->c_out % 4 == 0 && !res && d->act == UNET_ACT_NONE &&
                         k.y_vec && bn == 128 && (long long)d->l_out * d->y_ld * 2 < lim;
-    if (stream) return launch_stream(k, st);
-    if (v2) return bn == 128 ? launch_fwd2<128>(k, tg.rmax, st) : launch_fwd2<64>(k, tg.rmax, st);
+    if (stream) { g_last_variant = UNET_VARIANT_FWD_STREAM; return launch_stream(k, st); }
+    if (v2) {
+      g_last_variant = UNET_VARIANT_FWD_TILED;
+      return bn == 128 ? launch_fwd2<128>(k, tg.rmax, st) : launch_fwd2<64>(k, tg.rmax, st);
+    }
   }
+  g_last_variant = UNET_VARIANT_FWD_GENERIC;
   if (d->dtype == UNET_F32) return bn == 128 ? launch_fwd<true, 128>(k, tg.rmax, st) : launch_fwd<true, 64>(k, tg.rmax, st);
   return bn == 128 ? launch_fwd<false, 128>(k, tg.rmax, st) : launch_fwd<false, 64>(k, tg.rmax, st);
 }
@@ -1521,7 +1532,9 @@ extern "C" int unet_conv1d_wgrad(const UnetConvDesc* d, const void* x1, const vo
   UNET_REQUIRE(d->c2 == 0 || x2, "conv_wgrad: c2>0 but x2 is null");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long count = (long long)d->n_taps * d->c_out * (d->c1 + d->c2);
+  g_last_variant = UNET_VARIANT_WGRAD_GENERIC;
   if (wgrad2_ok(d, x1, x2, dy)) {
+    g_last_variant = UNET_VARIANT_WGRAD_PAIRED;
     WgGroups g;
     wgrad_groups(d, &g);
     const int splits = wgrad2_splits(d, ph, g.n);

@@ -63,6 +63,11 @@ def _f32c(t: Tensor) -> Tensor:
 PROFILE: Optional[list] = None
 
 
+# include/unet_hip.h UNET_VARIANT_*: the kernel the dispatcher picked for the launch just made
+_VARIANTS = {1: "conv_fwd_kernel", 2: "conv_fwd2_kernel", 3: "conv_stream_kernel", 11: "conv_wgrad_kernel",
+             12: "conv_wgrad2_kernel"}
+
+
 class _Timed:
     def __init__(self, kind: str, flops: float):
         self.on = PROFILE is not None
@@ -76,7 +81,8 @@ class _Timed:
     def __exit__(self, *exc):
         if self.on:
             self.rec[3].record()
-            PROFILE.append(self.rec)
+            variant = _VARIANTS.get(int(_lib.load().unet_conv1d_last_variant()), self.rec[0])
+            PROFILE.append((variant,) + self.rec[1:])
 
 
 def parts(rows: int) -> int:
