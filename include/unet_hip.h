@@ -87,7 +87,7 @@ int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void* x2, const
  * to attribute live launch timings to the kernel named in its roofline object. */
 enum { UNET_VARIANT_NONE = 0,
        UNET_VARIANT_FWD_GENERIC = 1,   /* conv_fwd_kernel: fp32 (exact 16x16x4 MFMA) or unaligned bf16 */
-       UNET_VARIANT_FWD_TILED = 2,     /* conv_fwd2_kernel_128/_64: bf16, buffer LDS-DMA, halo tile + tap loop */
+       UNET_VARIANT_FWD_TILED = 2,     /* conv_fwd2_kernel_192/_128/_64: bf16, buffer LDS-DMA, halo tile + tap loop */
        UNET_VARIANT_FWD_STREAM = 3,    /* conv_stream_kernel: bf16 single-tap convs, persistent, 256x128 tiles */
        UNET_VARIANT_WGRAD_GENERIC = 11,/* conv_wgrad_kernel */
        UNET_VARIANT_WGRAD_PAIRED = 12  /* conv_wgrad2_kernel: bf16, two taps per block, LDS-DMA ring */ };

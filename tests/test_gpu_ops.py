@@ -107,11 +107,12 @@ def test_conv_transpose(shape, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("L", [301, 570, 1150])   # 570 / 1150: lengths that select the 192-position tiles (fwd / 2-phase dgrad)
 @pytest.mark.parametrize("stride", [1, 2])
-def test_merged_dilated_concat(stride, dtype):
+def test_merged_dilated_concat(stride, dtype, L):
     """4-branch dilated conv (models.py:752-759) on a two-source (concat) input."""
     import unet_amd
-    n, c1, c2, cout, L = 2, 40, 24, 72, 301
+    n, c1, c2, cout = 2, 40, 24, 72
     torch.manual_seed(5)
     blk = unet_amd.MultiScaleDilatedConv1d(c1 + c2, cout, 7, stride, (1, 4, 16, 32))
     with torch.no_grad():

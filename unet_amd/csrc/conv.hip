@@ -507,6 +507,7 @@ __device__ __forceinline__ void conv_fwd2_body(const ConvK& p) {
 
 __global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_128(const ConvK p) { conv_fwd2_body<128>(p); }
 __global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_64(const ConvK p) { conv_fwd2_body<64>(p); }
+__global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_192(const ConvK p) { conv_fwd2_body<192>(p); }
 
 // ---------------------------------------------------------------------------------------------
 // Streaming kernel for single-tap (1x1) convolutions: FiLM q_proj / out_proj, skip_proj, residual_conv and
@@ -1262,16 +1263,18 @@ int launch_fwd2(ConvK& k, int rmax, hipStream_t st) {
   k.xbytes = xbytes;
   k.xdb = (2 * WTILE_BYTES + 2 * (size_t)xbytes <= 80 * 1024) ? 1 : 0;
   const size_t lds = 2 * WTILE_BYTES + (size_t)xbytes * (k.xdb ? 2 : 1);
+  const void* fn = BN == 192 ? reinterpret_cast<const void*>(&conv_fwd2_kernel_192)
+                 : BN == 128 ? reinterpret_cast<const void*>(&conv_fwd2_kernel_128)
+                             : reinterpret_cast<const void*>(&conv_fwd2_kernel_64);
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(BN == 128 ? reinterpret_cast<const void*>(&conv_fwd2_kernel_128)
-                                                 : reinterpret_cast<const void*>(&conv_fwd2_kernel_64),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     UNET_REQUIRE(e == hipSuccess, "conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     attr_set = true;
   }
   const long long blocks = (long long)k.mtiles * k.n * (k.ptiles[0] + k.ptiles[1]);
   UNET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv: grid of %lld blocks", blocks);
-  if (BN == 128) hipLaunchKernelGGL(conv_fwd2_kernel_128, dim3((unsigned)blocks), dim3(THREADS), lds, st, k);
+  if (BN == 192) hipLaunchKernelGGL(conv_fwd2_kernel_192, dim3((unsigned)blocks), dim3(THREADS), lds, st, k);
+  else if (BN == 128) hipLaunchKernelGGL(conv_fwd2_kernel_128, dim3((unsigned)blocks), dim3(THREADS), lds, st, k);
   else hipLaunchKernelGGL(conv_fwd2_kernel_64, dim3((unsigned)blocks), dim3(THREADS), lds, st, k);
   UNET_LAUNCH_CHECK("conv_fwd2");
   return 0;
@@ -1418,6 +1421,28 @@ extern "C" int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void
                         k.kctot >= 3 && d->c_out <= ST_MAXC && d->c_out % 4 == 0 && !res && d->act == UNET_ACT_NONE &&
                         k.y_vec && bn == 128 && (long long)d->l_out * d->y_ld * 2 < lim;
     if (stream) { g_last_variant = UNET_VARIANT_FWD_STREAM; return launch_stream(k, st); }
+    if (v2 && bn == 128) {
+      // 192 positions per tile (2/3 of the weight bytes and LDS-DMA instructions per FLOP) for many-tap convs when
+      // the halo tile still leaves two workgroups per CU and the last, partial tile wastes under 4 % of the work
+      const char* envb = getenv("UNET_CONV_BN");
+      bool want = d->n_taps >= 8 && !(envb && atoi(envb) == 128);
+      for (int r = 0; r < d->up && want; ++r)
+        want = ph.mcount[r] > 0 && (long long)cdiv(ph.mcount[r], 192) * 192 * 100 <= (long long)ph.mcount[r] * 104;
+      if (want) {
+        TileGeom tg2;
+        tile_geom(d, ph, 192, &tg2);
+        const int pieces = (tg2.rmax + 7) / 8;
+        if (pieces <= 4 * F2_MAXP && 2 * WTILE_BYTES + (size_t)pieces * 1024 <= 80 * 1024) {
+          for (int r = 0; r < 2; ++r) {
+            k.ptiles[r] = (r < d->up) ? cdiv(ph.mcount[r], 192) : 0;
+            for (int c = 0; c < 2; ++c) { k.seg_rows[r][c] = tg2.seg_rows[r][c]; k.seg_q0[r][c] = tg2.seg_q0[r][c]; }
+          }
+          for (int j = 0; j < UNET_MAX_TAPS; ++j) k.tap_row[j] = tg2.tap_row[j];
+          g_last_variant = UNET_VARIANT_FWD_TILED;
+          return launch_fwd2<192>(k, tg2.rmax, st);
+        }
+      }
+    }
     if (v2) {
       g_last_variant = UNET_VARIANT_FWD_TILED;
       return bn == 128 ? launch_fwd2<128>(k, tg.rmax, st) : launch_fwd2<64>(k, tg.rmax, st);
