@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/metrics.npz and tests/golden/host_logic.json.
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/metrics.npz, host_logic.json, overlap_add.npz, checkpoint_layout.json.
 
 Runs ONLY in the build container (reference mounted at /root/reference): imports the reference's own
 ``models.py`` / ``utils/dsp_metrics.py`` / ``phase_five/sliding_window.py`` / ``phase_four/data_splitter.py``
@@ -158,6 +158,47 @@ def host_logic():
     print("host_logic.json written")
 
 
+def checkpoint_layout():
+    """Layout of the file the reference's save_checkpoint writes (train.py:652-701) and load_checkpoint's
+    behaviour on a cond_mode mismatch (train.py:523-534), on a tiny module."""
+    import tempfile
+    from pathlib import Path
+    import train as ref_train
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    model(torch.randn(5, 4)).sum().backward()
+    opt.step()
+    config = {"cond_mode": "cross_attn_gated", "lr": 1e-3, "checkpoint_prefix": "fold3", "base_channels": 256}
+    data = {"split_info": {"test_sessions": ["s1"], "n_val": 2}, "val_idx": np.arange(3), "test_idx": np.array([7, 8]),
+            "train_idx": [0, 1, 2]}
+    d = Path(tempfile.mkdtemp(prefix="unet_ckpt_"))
+    ref_train.save_checkpoint(model, opt, 7, d / "a.pt", config=config, data=data)
+    ck = torch.load(d / "a.pt", map_location="cpu", weights_only=True)        # our own freshly written file
+    out = {"keys": sorted(ck.keys()), "epoch": ck["epoch"], "cond_mode": ck["cond_mode"], "config": ck["config"],
+           "split_info": ck["split_info"], "model_keys": list(ck["model"].keys()),
+           "optimizer_keys": sorted(ck["optimizer"].keys()),
+           "optimizer_state_keys": sorted(ck["optimizer"]["state"][0].keys())}
+    ref_train.save_checkpoint(model, opt, 1, d / "b.pt")
+    ck = torch.load(d / "b.pt", map_location="cpu", weights_only=True)
+    out["keys_minimal"] = sorted(ck.keys())
+    out["cond_mode_minimal"] = ck["cond_mode"]
+    m2 = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+    out["load_returns"] = ref_train.load_checkpoint(d / "a.pt", m2, expected_cond_mode="cross_attn_gated")
+    out["loaded_equal"] = bool(all(torch.equal(a, b) for a, b in zip(m2.state_dict().values(), model.state_dict().values())))
+    try:
+        ref_train.load_checkpoint(d / "a.pt", m2, expected_cond_mode="film")
+        out["mismatch_error"] = None
+    except ValueError as e:
+        out["mismatch_error"] = str(e)
+    try:
+        ref_train.load_checkpoint(d / "missing.pt", m2)
+    except FileNotFoundError as e:
+        out["missing_error"] = str(e).replace(str(d), "<dir>")
+    json.dump(out, open(os.path.join(OUT, "checkpoint_layout.json"), "w"), indent=1)
+    print("checkpoint_layout.json written")
+
+
 def main():
     import tempfile
     # the reference's split helper saves .npy files under UNET_DATA_DIR (data.py:88, 803-808): point it at a scratch dir
@@ -167,8 +208,12 @@ def main():
     import models as ref
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    if "--only-checkpoint" in sys.argv:
+        checkpoint_layout()
+        return
     metrics(ref)
     host_logic()
+    checkpoint_layout()
 
 
 if __name__ == "__main__":

@@ -87,6 +87,46 @@ def test_trainer_step_matches_oracle_and_learns():
         tr.step(ob.cuda() * float("nan"), tgt.cuda(), ids.cuda())
 
 
+def test_fit_checkpoint_early_stop_roundtrip(tmp_path):
+    """Epoch loop protocol (train.py:2434-2757): best checkpoint, history rows, early stop; the saved file loads
+    back into a fresh model (strict) and reproduces the validation metrics; results JSON carries the LOSO keys."""
+    import unet_amd
+    from unet_amd import checkpoint as ck
+    from unet_amd.trainer import Trainer
+    cfg = dict(in_channels=8, out_channels=8, base=16, emb_dim=32, conv_type="modern", attention_type="none", activation="gelu")
+    torch.manual_seed(1)
+    model = unet_amd.CondUNet1D(**cfg).cuda()
+    with torch.no_grad():
+        model.outc.weight.normal_(0, 0.05)
+    g = torch.Generator().manual_seed(0)
+    ob, tgt = torch.randn(4, 8, 4608, generator=g).cuda(), (torch.randn(4, 8, 4608, generator=g) * 2 + 1).cuda()
+    ids = torch.tensor([0, 1, 2, 3]).cuda()
+    tr = Trainer(model, lr=1e-3, compute_dtype=torch.float32)
+    config = {"cond_mode": "cross_attn_gated", "checkpoint_prefix": "fold0"}
+    out = tr.fit(lambda epoch: [(ob, tgt, ids)] * 2, lambda: [(ob, tgt, ids)], num_epochs=3, early_stop_patience=8,
+                 checkpoint_dir=tmp_path, config=config, data={"val_idx": np.arange(4)}, test_batches=lambda: [(ob, tgt, ids)])
+    assert [h["epoch"] for h in out["history"]] == [1, 2, 3]
+    assert {"loss", "l1_fwd", "val_loss", "val_r2", "val_corr", "val_mae", "val_mse"} <= set(out["history"][0])
+    assert out["best_epoch"] == 3 and out["best_val_loss"] == out["history"][2]["val_loss"]      # it learns every epoch
+    path = tmp_path / "fold0_best_model.pt"
+    assert path.exists()
+    saved = torch.load(path, map_location="cpu", weights_only=True)
+    assert saved["epoch"] == 3 and saved["split_info"] == {"val_idx": [0, 1, 2, 3]} and saved["cond_mode"] == "cross_attn_gated"
+    fresh = unet_amd.CondUNet1D(**cfg).cuda()
+    assert ck.load_checkpoint(path, fresh, expected_cond_mode="cross_attn_gated") == "cross_attn_gated"
+    res = Trainer(fresh, compute_dtype=torch.float32).evaluate([(ob, tgt, ids)])
+    assert abs(res["loss"] - out["best_val_loss"]) < 1e-6
+    js = ck.results_json(out, "condunet", 0)
+    assert js["best_epoch"] == 3 and js["epochs_trained"] == 3 and js["test_avg_r2"] == out["test_metrics"]["r2"]
+    assert js["best_val_r2"] == out["history"][2]["val_r2"] and js["n_parameters"] == sum(p.numel() for p in model.parameters())
+    # early stop: a learning rate of zero (and no running statistics) never improves after the first epoch
+    # -> stops at epoch 1 + patience
+    frozen = unet_amd.CondUNet1D(**dict(cfg, norm_type="instance")).cuda()
+    tr0 = Trainer(frozen, lr=0.0, compute_dtype=torch.float32)
+    out0 = tr0.fit(lambda epoch: [(ob, tgt, ids)], lambda: [(ob, tgt, ids)], num_epochs=10, early_stop_patience=2)
+    assert out0["best_epoch"] == 1 and len(out0["history"]) == 3
+
+
 def test_config_c_wide_deep_vs_oracle():
     """BASELINE configs[2] shape family: 128 input/output channels, n_downsample=4 (channel ladder capped at
     8*base), at a base the oracle finishes in seconds."""

@@ -21,6 +21,7 @@ import torch
 import torch.distributed as dist
 
 from . import metrics
+from .checkpoint import EarlyStopping, checkpoint_name, history_entry, save_checkpoint
 from .dp import BucketedGradAllReduce, broadcast_parameters
 from .folds import LOSOJob, aggregate_folds, aggregate_seed_results, assign_jobs, loso_jobs
 
@@ -120,6 +121,56 @@ class Trainer:
             out["psd_diagnostics"] = diag
         out["loss"] = self.weight_l1 * out["mae"]                               # train.py:1271-1282
         return out
+
+
+    def train_epoch(self, batches: Iterable[Sequence[torch.Tensor]]) -> Dict[str, float]:
+        """train.py:1395-1580: mean of the per-batch losses, accumulated on the device (one host read per epoch)."""
+        total, n = None, 0
+        for batch in batches:
+            ob, target = batch[0], batch[1]
+            ids = batch[2] if len(batch) > 2 else None
+            loss = self.step(ob, target, ids).detach()
+            total = loss.clone() if total is None else total + loss
+            n += 1
+        self.check_finite()
+        if n == 0:
+            return {"loss": 0.0}                                              # train.py:1568-1574
+        l1 = float(total.item()) / n
+        return {"loss": l1, "l1_fwd": l1}
+
+    def fit(self, train_batches: Callable[[int], Iterable], val_batches: Callable[[], Iterable], num_epochs: int,
+            early_stop_patience: int = 8, checkpoint_dir=None, config: Optional[dict] = None, data: Optional[dict] = None,
+            test_batches: Optional[Callable[[], Iterable]] = None) -> Dict[str, object]:
+        """Epoch loop of train.py:2434-2757 for the path in scope: train, validate (pooled metrics), average the
+        val loss over ranks, keep the best checkpoint (strict <), append the history row, stop after
+        ``early_stop_patience`` epochs without improvement (rank 0's decision, broadcast).  ``train_batches(epoch)``
+        and ``val_batches()`` return iterables of ``(ob, target[, odor_ids])`` device batches.  Returns what
+        ``train()`` returns (train.py:3290-3299), ready for ``checkpoint.results_json``."""
+        import time
+        from pathlib import Path
+        t0 = time.time()
+        dev = next(self.model.parameters()).device
+        stopper = EarlyStopping(early_stop_patience, self.pg)
+        history: List[dict] = []
+        for epoch in range(1, num_epochs + 1):
+            train_metrics = self.train_epoch(train_batches(epoch))
+            val_metrics = self.evaluate(val_batches())
+            val_loss = val_metrics.get("loss", val_metrics.get("mae", float("inf")))
+            val_loss = stopper.sync_val_loss(val_loss, dev)
+            val_metrics["loss"] = val_loss
+            if stopper.update(val_loss, epoch) and checkpoint_dir is not None:
+                save_checkpoint(self.model, self.opt, epoch, Path(checkpoint_dir) / checkpoint_name(config), config=config,
+                                data=data, process_group=self.pg)
+            if dist.is_available() and dist.is_initialized():
+                dist.barrier(group=self.pg)
+            history.append(history_entry(epoch, train_metrics, val_metrics))
+            if stopper.should_stop(dev):
+                break
+        test_metrics = self.evaluate(test_batches(), fast_mode=False) if test_batches is not None else {}
+        return {"best_val_loss": stopper.best_val_loss, "best_epoch": stopper.best_epoch, "test_metrics": test_metrics,
+                "history": history, "model": self.model, "reverse_model": None,
+                "n_parameters": sum(p.numel() for p in self.model.parameters() if p.requires_grad),
+                "total_time": time.time() - t0}
 
 
 def run_loso(all_sessions: Sequence[str], run_fold: Callable[[LOSOJob], Dict[str, float]], seed: int = 42,
