@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=16, help="windows per CPU-baseline step (2 steps are timed)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--conditioning", default="odor_onehot", choices=["odor_onehot", "spectro_temporal"],
+                    help="spectro_temporal: the SpectroTemporalEncoder (train.py --conditioning default) runs inside the "
+                         "step and trains with the model; the headline config is odor_onehot")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one (hook-driven overlapped "
                     "all-reduce) instead of replaying the captured HIP graph")
     return ap.parse_args()
@@ -108,13 +111,23 @@ def main():
     with torch.no_grad():  # the reference zero-initialises outc; give it values so backward is not trivially zero
         model.outc.weight.normal_(0, 0.02)
     model = model.to(dev)
+    from unet_amd.dp import coalesced_grad_mean
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.set_compute_dtype(cdt)
     model.train()
     broadcast_parameters(model)
     n_params = sum(p.numel() for p in model.parameters())
 
-    opt = torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.7595905764360957, 0.920298282605139),
+    enc = None
+    groups = [{"params": list(model.parameters())}]
+    if args.conditioning == "spectro_temporal":
+        from unet_amd.cond import SpectroTemporalEncoder
+        enc = SpectroTemporalEncoder(in_channels=32, emb_dim=128).to(dev)
+        enc.set_compute_dtype(cdt)
+        enc.eval()                                                         # train.py:1410-1411
+        broadcast_parameters(enc)
+        groups.append({"params": list(enc.parameters()), "name": "cond_encoder"})  # train.py:2225-2227
+    opt = torch.optim.AdamW(groups, lr=2e-4, betas=(0.7595905764360957, 0.920298282605139),
                             weight_decay=0.0, fused=True, capturable=not args.eager)  # train.py:183-193
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -134,14 +147,16 @@ def main():
     if not args.eager:
         try:
             from unet_amd.graphs import GraphedTrainStep
-            graphed = GraphedTrainStep(model, loss_fn, opt, [ob, ids], [tgt], clip_norm=5.0)
+            fwd = (lambda o, i: model(o, i, cond_emb=enc(o))) if enc is not None else None
+            graphed = GraphedTrainStep(model, loss_fn, opt, [ob, ids], [tgt], clip_norm=5.0, forward=fwd,
+                                       extra_modules=[enc] if enc is not None else [])
             mode = "hipgraph"
         except Exception as e:  # capture unsupported in this environment: run the same step eagerly
             import traceback
             traceback.print_exc()
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}); running eagerly", file=sys.stderr)
             graphed = None
-            opt = torch.optim.AdamW(model.parameters(), lr=2e-4, betas=(0.7595905764360957, 0.920298282605139),
+            opt = torch.optim.AdamW(groups, lr=2e-4, betas=(0.7595905764360957, 0.920298282605139),
                                     weight_decay=0.0, fused=True)
     if graphed is None:
         reducer = BucketedGradAllReduce(model.parameters())
@@ -150,10 +165,16 @@ def main():
         if graphed is not None:
             return graphed()
         reducer.zero_grad()
-        loss = loss_fn(model(ob, ids), tgt)
+        if enc is not None:
+            for p in enc.parameters():
+                p.grad = None
+        loss = loss_fn(model(ob, ids, cond_emb=enc(ob)) if enc is not None else model(ob, ids), tgt)
         loss.backward()
         reducer.finish()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)  # train.py:1553 GRAD_CLIP
+        if enc is not None:                                      # train.py:1556-1558
+            torch.nn.utils.clip_grad_norm_(enc.parameters(), 5.0)
+            coalesced_grad_mean(list(enc.parameters()))
         opt.step()
         return loss
 
@@ -184,7 +205,7 @@ def main():
         # region; profiles/ holds the rocprofv3 summary of the graph replay itself for cross-checking.
         ops.PROFILE = []
         for _ in range(min(3, args.steps)):
-            loss_fn(model(ob, ids), tgt).backward()
+            loss_fn(model(ob, ids, cond_emb=enc(ob)) if enc is not None else model(ob, ids), tgt).backward()
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
         prof_steps = min(3, args.steps)
@@ -206,7 +227,7 @@ def main():
         "config": {"workload": "config B: CondUNet1D train.py/LOSO default (base=256, modern 4x dilated k7 + SE, FiLM, "
                                "skip add, BN), 32ch x 4096 windows, 64 windows/GPU, fwd + L1[500:4500] + bwd + "
                                "grad all-reduce + clip 5.0 + AdamW", "windows_per_gpu": B, "params": n_params,
-                   "parallelism": f"dp{world}", "launch": mode},
+                   "parallelism": f"dp{world}", "launch": mode, "conditioning": args.conditioning},
         "final_loss": float(loss.item()), "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
         "ms_each_step": [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(args.steps)],
         "model_tflops_algorithmic": value * 3 * GFLOP_PER_WINDOW_FWD / 1e3,

@@ -233,6 +233,13 @@ int unet_psd_db_stats(const float* psd_pred, const float* psd_target, int64_t ro
 int unet_band_power(const float* psd, int64_t rows, int32_t nfreq, int32_t n_bands, const int32_t* lo_host,
                     const int32_t* hi_host, int32_t mode, float df, float* out, void* stream);
 
+/* Log band power of a one-sided complex spectrum: out[row][k] = log(sum_f |X[row][f]|^2 * masks[k][f] + eps),
+ * the einsum('bcf,kf->bck') + log of SpectroTemporalEncoder._spectral_forward (models.py:1294-1301).
+ * spectrum: rows x nfreq interleaved (re, im) fp32 (torch.fft.rfft output); masks: n_bands x nfreq fp32
+ * (models.py:1245-1275); n_bands <= 16. */
+int unet_band_log_power(const float* spectrum, const float* masks, int64_t rows, int32_t nfreq, int32_t n_bands,
+                        float eps, float* out, void* stream);
+
 /* phase_five/sliding_window.py:238-251 overlap-average reconstruction.  pred[w][c][window_size] holds windows
  * first_window .. first_window+n_windows-1 of total_windows (window g starts at g*stride);
  * mode 0 "average": out[c][n_samples] (+)= their sum per sample (accumulate: add to what out holds, so

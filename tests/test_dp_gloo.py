@@ -140,3 +140,41 @@ def test_fold_parallel_loso_two_ranks():
     assert abs(res[0][2][1] - 0.105) < 1e-12
     assert abs(res[0][1]["mean_r2"] - 0.105) < 1e-12
     assert abs(res[0][1]["mean_loss"] - (42 + 43 + 44 + 45 + 46 + 47) / 6) < 1e-12
+
+
+def _coalesce_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unet_amd.dp import coalesced_grad_mean
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.LayerNorm(7), torch.nn.Linear(7, 2))
+    extra = torch.nn.Parameter(torch.ones(3))               # no gradient: skipped
+    torch.manual_seed(50 + rank)
+    m(torch.randn(6, 5)).square().sum().backward()
+    local = [p.grad.clone() for p in m.parameters()]
+    coalesced_grad_mean(list(m.parameters()) + [extra])
+    q.put((rank, [g.numpy().copy() for g in local], [p.grad.numpy().copy() for p in m.parameters()], extra.grad is None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_coalesced_grad_mean_two_ranks():
+    """One flattened all-reduce == the reference's per-parameter sync_gradients_manual (train.py:738-758)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_coalesce_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, local, reduced, none_kept = q.get(timeout=120)
+        res[rank] = (local, reduced, none_kept)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for i in range(len(res[0][0])):
+        want = (res[0][0][i] + res[1][0][i]) / 2
+        assert torch.allclose(torch.from_numpy(res[0][1][i]), torch.from_numpy(want), atol=1e-7)
+        assert (res[0][1][i] == res[1][1][i]).all()
+    assert res[0][2] and res[1][2]

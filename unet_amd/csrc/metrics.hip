@@ -288,6 +288,38 @@ __global__ __launch_bounds__(THREADS) void band_power_kernel(const float* psd, l
 // out[c][n_samples] (+)= ..., gather form: each output sample adds the windows covering it in window
 // order (deterministic), divides by max(count,1) when `finalize` (sliding_window.py:238-251).
 // ---------------------------------------------------------------------------------------------
+// log band power of a one-sided spectrum (SpectroTemporalEncoder._spectral_forward, models.py:1294-1301):
+// out[row][k] = log( sum_f |X[row][f]|^2 * mask[k][f] + eps ).  One workgroup per row, lanes stride over f (the
+// complex spectrum is read once, 8 bytes per bin, coalesced); K <= 16 running sums per lane in fp32, summed
+// across the workgroup in fp64.
+constexpr int BLP_MAXK = 16;
+__global__ __launch_bounds__(THREADS) void band_log_power_kernel(const float2* spec, const float* masks, float* out,
+                                                                 int nfreq, int nbands, float eps) {
+  __shared__ double red[BLP_MAXK * (THREADS / 64)];
+  const long long row = blockIdx.x;
+  const float2* x = spec + row * nfreq;
+  float acc[BLP_MAXK];
+#pragma unroll
+  for (int k = 0; k < BLP_MAXK; ++k) acc[k] = 0.f;
+  for (int f = threadIdx.x; f < nfreq; f += THREADS) {
+    const float2 v = x[f];
+    const float pw = v.x * v.x + v.y * v.y;
+#pragma unroll
+    for (int k = 0; k < BLP_MAXK; ++k)
+      if (k < nbands) acc[k] = fmaf(pw, masks[(long long)k * nfreq + f], acc[k]);
+  }
+  double d[BLP_MAXK];
+#pragma unroll
+  for (int k = 0; k < BLP_MAXK; ++k) d[k] = (double)acc[k];
+  block_sum_d<BLP_MAXK>(d, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < BLP_MAXK; ++k)
+      if (k < nbands) out[row * nbands + k] = logf((float)d[k] + eps);
+  }
+}
+
+
 template <typename T>
 __global__ __launch_bounds__(THREADS) void overlap_add_kernel(const T* pred, int n_win, int w0, int total_win, int c,
                                                                int wsize, int stride, long long n_samples, float* out,
@@ -473,5 +505,18 @@ extern "C" int unet_overlap_add(int32_t dtype, const void* pred, int32_t n_windo
                        accumulate, finalize, mode);
   })
   UNET_LAUNCH_CHECK("overlap_add");
+  return 0;
+}
+
+extern "C" int unet_band_log_power(const float* spectrum, const float* masks, int64_t rows, int32_t nfreq, int32_t n_bands,
+                                   float eps, float* out, void* stream) {
+  UNET_REQUIRE(spectrum && masks && out, "band_log_power: null pointer");
+  UNET_REQUIRE(rows >= 0 && rows < (1ll << 31) && nfreq > 0, "band_log_power: bad shape rows=%lld nfreq=%d", (long long)rows, nfreq);
+  UNET_REQUIRE(n_bands >= 1 && n_bands <= BLP_MAXK, "band_log_power: n_bands %d outside 1..%d", n_bands, BLP_MAXK);
+  UNET_REQUIRE((reinterpret_cast<uintptr_t>(spectrum) & 7) == 0, "band_log_power: spectrum must be 8-byte aligned");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(band_log_power_kernel, dim3((unsigned)rows), dim3(THREADS), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float2*>(spectrum), masks, out, nfreq, n_bands, eps);
+  UNET_LAUNCH_CHECK("band_log_power");
   return 0;
 }

@@ -125,3 +125,27 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=No
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t, src=src, group=process_group)
+
+
+def coalesced_grad_mean(params, process_group=None):
+    """Mean of the gradients of a SMALL module across ranks in ONE message -- the reference's
+    ``sync_gradients_manual`` (train.py:738-758) issues one all-reduce per parameter (28 tiny collectives for the
+    conditioning encoder); xGMI collectives are latency-bound at that size, so the gradients are flattened into
+    one fp32 buffer, reduced once and copied back.  No-op without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world = dist.get_world_size(process_group)
+    if world == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.detach().reshape(-1).float() for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
+    flat.div_(world)
+    off = 0
+    with torch.no_grad():
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n

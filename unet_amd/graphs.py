@@ -31,9 +31,14 @@ class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, loss_fn: Callable, optimizer: torch.optim.Optimizer,
                  inputs: Sequence[torch.Tensor], targets: Sequence[torch.Tensor], clip_norm: Optional[float] = None,
                  warmup: int = 3, process_group=None, bucket_bytes: int = 64 << 20,
-                 forward: Optional[Callable] = None):
+                 forward: Optional[Callable] = None, extra_modules: Sequence[torch.nn.Module] = ()):
+        """``extra_modules``: small modules trained in the same step (the conditioning encoder).  As in the
+        reference (train.py:1553-1558) each gets its own clip, applied per rank BEFORE its gradients are averaged,
+        whereas the model's clip follows the all-reduce."""
         self.model, self.loss_fn, self.opt, self.clip = model, loss_fn, optimizer, clip_norm
-        self.params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
+        self.model_params: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad]
+        self.extra_params = [[p for p in m.parameters() if p.requires_grad] for m in extra_modules]
+        self.params: List[torch.nn.Parameter] = self.model_params + [p for grp in self.extra_params for p in grp]
         self.static_in = [t.clone() for t in inputs]
         self.static_tg = [t.clone() for t in targets]
         self.pg = process_group
@@ -43,11 +48,14 @@ class GraphedTrainStep:
             out = (forward or model)(*self.static_in)
             loss = loss_fn(out, *self.static_tg)
             loss.backward()
+            if self.clip is not None:
+                for grp in self.extra_params:
+                    torch.nn.utils.clip_grad_norm_(grp, self.clip)
             return loss
 
         def update():
             if self.clip is not None:
-                torch.nn.utils.clip_grad_norm_(self.params, self.clip)
+                torch.nn.utils.clip_grad_norm_(self.model_params, self.clip)
             self.opt.step()
 
         # warm-up on a side stream (allocator pools, lazy kernel attributes, optimizer state)

@@ -22,7 +22,7 @@ import torch.distributed as dist
 
 from . import metrics
 from .checkpoint import EarlyStopping, checkpoint_name, history_entry, save_checkpoint
-from .dp import BucketedGradAllReduce, broadcast_parameters
+from .dp import BucketedGradAllReduce, broadcast_parameters, coalesced_grad_mean
 from .folds import LOSOJob, aggregate_folds, aggregate_seed_results, assign_jobs, loso_jobs
 
 GRAD_CLIP = 5.0                                             # train.py:235
@@ -32,16 +32,24 @@ DEFAULT_BETAS = (0.7595905764360957, 0.920298282605139)     # train.py:186-188
 class Trainer:
     def __init__(self, model: torch.nn.Module, lr: float = 2e-4, betas=DEFAULT_BETAS, weight_decay: float = 0.0,
                  weight_l1: float = 1.0, grad_clip: float = GRAD_CLIP, compute_dtype: Optional[torch.dtype] = torch.bfloat16,
-                 use_graph: bool = False, bucket_bytes: int = 64 << 20, nan_check_every: int = 50, process_group=None):
+                 use_graph: bool = False, bucket_bytes: int = 64 << 20, nan_check_every: int = 50, process_group=None,
+                 cond_encoder: Optional[torch.nn.Module] = None):
         self.model = model
+        self.cond_encoder = cond_encoder          # train.py:2026-2030 (--conditioning spectro_temporal)
         if compute_dtype is not None and hasattr(model, "set_compute_dtype"):
             model.set_compute_dtype(compute_dtype)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         broadcast_parameters(model, process_group=process_group)
+        groups = [{"params": list(model.parameters()), "lr": lr}]
+        if cond_encoder is not None:
+            broadcast_parameters(cond_encoder, process_group=process_group)
+            if compute_dtype is not None and hasattr(cond_encoder, "set_compute_dtype"):
+                cond_encoder.set_compute_dtype(compute_dtype)
+            groups.append({"params": list(cond_encoder.parameters()), "lr": lr, "name": "cond_encoder"})  # train.py:2225-2227
         self.weight_l1, self.grad_clip = weight_l1, grad_clip
         self.use_graph = use_graph
-        self.opt = torch.optim.AdamW(model.parameters(), lr=lr, betas=betas, weight_decay=weight_decay, fused=True,
+        self.opt = torch.optim.AdamW(groups, lr=lr, betas=betas, weight_decay=weight_decay, fused=True,
                                      capturable=use_graph)
         self.reducer = None if use_graph else BucketedGradAllReduce(model.parameters(), bucket_bytes, process_group)
         self._graphed = None
@@ -49,6 +57,18 @@ class Trainer:
         self.nan_check_every = nan_check_every
         self._steps = 0
         self._bad = None
+
+    def _cond(self, ob: torch.Tensor) -> Optional[torch.Tensor]:
+        """train.py:1409-1414: the encoder runs in eval() (running BatchNorm statistics, no dropout) even while
+        its weights train."""
+        enc = self.cond_encoder
+        if enc is None:
+            return None
+        was_training = enc.training
+        enc.eval()
+        emb = enc(ob)
+        enc.train(was_training)
+        return emb
 
     def _loss(self, pred, target):
         return metrics.l1_crop_loss(pred, target, self.weight_l1)
@@ -64,19 +84,30 @@ class Trainer:
                 from .graphs import GraphedTrainStep
                 if cond_emb is not None:
                     fwd = lambda o, e: self.model(o, cond_emb=e)
+                elif self.cond_encoder is not None:
+                    fwd = lambda o, *i: self.model(o, *i, cond_emb=self._cond(o))
                 else:
                     fwd = lambda o, *i: self.model(o, *i)
+                extra = [self.cond_encoder] if (self.cond_encoder is not None and cond_emb is None) else []
                 self._graphed = GraphedTrainStep(self.model, self._loss, self.opt, [ob] + cond, [tgt],
                                                  clip_norm=self.grad_clip, process_group=self.pg,
-                                                 bucket_bytes=self._bucket_bytes, forward=fwd)
+                                                 bucket_bytes=self._bucket_bytes, forward=fwd, extra_modules=extra)
             loss = self._graphed([ob] + cond, [tgt])
         else:
             self.reducer.zero_grad()
+            if self.cond_encoder is not None:
+                for p in self.cond_encoder.parameters():
+                    p.grad = None
+                if cond_emb is None:
+                    cond_emb = self._cond(ob)
             pred = self.model(ob, odor_ids, cond_emb=cond_emb) if cond_emb is not None else self.model(ob, odor_ids)
             loss = self._loss(pred, tgt)
             loss.backward()
             self.reducer.finish()
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip)
+            if self.cond_encoder is not None:                      # train.py:1556-1558: clip per rank, then average
+                torch.nn.utils.clip_grad_norm_(self.cond_encoder.parameters(), self.grad_clip)
+                coalesced_grad_mean(list(self.cond_encoder.parameters()), self.pg)
             self.opt.step()
         bad = ~torch.isfinite(loss.detach())
         self._bad = bad if self._bad is None else (self._bad | bad)
@@ -101,7 +132,8 @@ class Trainer:
             ob, target = batch[0], batch[1]
             ids = batch[2] if len(batch) > 2 else None
             tgt = metrics.per_channel_normalize(target)
-            pred = self.model(ob, ids)
+            emb = self._cond(ob)
+            pred = self.model(ob, ids, cond_emb=emb) if emb is not None else self.model(ob, ids)
             pc, tc = metrics.crop_to_target_torch(pred).float(), metrics.crop_to_target_torch(tgt).float()
             if stats is None:
                 stats = metrics.PooledStats(ob.device)
