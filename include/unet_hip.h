@@ -251,6 +251,28 @@ int unet_overlap_add(int32_t dtype, const void* pred, int32_t n_windows, int32_t
                      int32_t c, int32_t window_size, int32_t stride, int64_t n_samples, float* out, float* counts,
                      int32_t accumulate, int32_t finalize, int32_t mode, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Data path in front of the model (csrc/data.hip).
+ *
+ * unet_gather_windows: out[b][ch][:] = src[ch][starts[b] : starts[b]+w], optionally z-scored per (window, channel)
+ * row with numpy's biased std: (x - mean) / (std + eps) -- ECoGDataset.__getitem__ (data.py:4586-4612) and the
+ * per-window normalisation of data.py:3120-3124 for a whole batch.  src: c rows of pitch src_ld elements holding
+ * src_len valid samples (recordings concatenated along time); starts_dev: n_windows int64 on the device,
+ * each in [0, src_len - w] (the caller builds them from the reference's window table, unet_amd/windows.py).
+ *
+ * unet_noise_augment: NoiseAugmentor.forward (models.py:4897-4946) after the random draws:
+ *   y = (x + gauss*scales[0] + pink*scales[1]) * [channel_u > channel_p] * [time_u > time_p]
+ *       + line_amp[b] * sin(2*pi*line_hz * t_i + line_phase[b]),   t_i = torch.linspace(0, t/sample_rate, t)[i] (fp32)
+ * x, gauss, pink, y: [n][c][t] of `dtype`; any of gauss / pink / channel_u [n*c] / time_u [n*t] / line_amp [n]
+ * may be null (that term is skipped); scales_dev: 2 floats on the device (no host read of the data's std). */
+int unet_gather_windows(int32_t in_dtype, int32_t out_dtype, const void* src, int64_t src_ld, int64_t src_len,
+                        const int64_t* starts_dev, int32_t n_windows, int32_t c, int32_t w, int32_t zscore,
+                        float eps, void* out, void* stream);
+int unet_noise_augment(int32_t dtype, const void* x, const void* gauss, const void* pink, const float* scales_dev,
+                       const float* channel_u, float channel_p, const float* time_u, float time_p,
+                       const float* line_amp, const float* line_phase, float line_hz, float sample_rate,
+                       int32_t n, int32_t c, int32_t t, void* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

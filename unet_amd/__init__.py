@@ -6,6 +6,7 @@ Public surface mirrors the reference's ``models.py`` for the path in scope:
 from .model import (CondUNet1D, ConvBlock, UpBlock, ModernConvBlock, ModernUpBlock, MultiScaleDilatedConv1d,
                     DilatedConv1d, SqueezeExcitation1D, FiLM, SelfAttention1D, SessionAdaptiveScaling)
 from .cond import SpectroTemporalEncoder
+from .augment import NoiseAugmentor
 
-__all__ = ["SpectroTemporalEncoder", "CondUNet1D", "ConvBlock", "UpBlock", "ModernConvBlock", "ModernUpBlock", "MultiScaleDilatedConv1d",
+__all__ = ["SpectroTemporalEncoder", "NoiseAugmentor", "CondUNet1D", "ConvBlock", "UpBlock", "ModernConvBlock", "ModernUpBlock", "MultiScaleDilatedConv1d",
            "DilatedConv1d", "SqueezeExcitation1D", "FiLM", "SelfAttention1D", "SessionAdaptiveScaling"]

@@ -33,8 +33,9 @@ class Trainer:
     def __init__(self, model: torch.nn.Module, lr: float = 2e-4, betas=DEFAULT_BETAS, weight_decay: float = 0.0,
                  weight_l1: float = 1.0, grad_clip: float = GRAD_CLIP, compute_dtype: Optional[torch.dtype] = torch.bfloat16,
                  use_graph: bool = False, bucket_bytes: int = 64 << 20, nan_check_every: int = 50, process_group=None,
-                 cond_encoder: Optional[torch.nn.Module] = None):
+                 cond_encoder: Optional[torch.nn.Module] = None, noise_augmentor: Optional[torch.nn.Module] = None):
         self.model = model
+        self.noise_augmentor = noise_augmentor    # train.py:2310-2328; applied to the input only, in train mode
         self.cond_encoder = cond_encoder          # train.py:2026-2030 (--conditioning spectro_temporal)
         if compute_dtype is not None and hasattr(model, "set_compute_dtype"):
             model.set_compute_dtype(compute_dtype)
@@ -77,6 +78,9 @@ class Trainer:
              cond_emb: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One optimisation step on a batch of windows; returns the (device) loss."""
         self.model.train()
+        if self.noise_augmentor is not None:      # train.py:1401-1402 (host-side coin flip: stays outside the graph)
+            self.noise_augmentor.train()
+            ob = self.noise_augmentor(ob)
         tgt = metrics.per_channel_normalize(target)
         if self.use_graph:
             cond = [cond_emb] if cond_emb is not None else ([odor_ids] if odor_ids is not None else [])

@@ -86,3 +86,71 @@ def shard_windows(total_windows: int, world_size: int, window_size: int, stride:
         out.append(WindowShard(r, first, n, lo, hi))
         first += n
     return out
+
+
+class DeviceRecordings:
+    """Recordings resident in HBM + batch assembly in one kernel (``unet_gather_windows``).
+
+    The reference's ``ECoGDataset`` (data.py:4574-4612) keeps recordings on the host and ``__getitem__`` slices,
+    optionally z-scores and copies ONE window at a time; a DataLoader then stacks and uploads them.  Here every
+    recording is uploaded once (channels pre-sliced to the common counts as data.py:4584-4611 does, recordings
+    concatenated along time), the window table is the reference's (``ecog_windows``), and ``batch(indices)``
+    gathers -- and, if asked, per-window z-scores (numpy's biased std, + 1e-8) -- a whole batch on the device.
+    """
+
+    def __init__(self, subjects_data, window_size: int = 5000, stride: int = 2500, zscore_per_window: bool = False,
+                 n_source_channels=None, n_target_channels=None, device="cuda", dtype=None):
+        import numpy as np
+        import torch
+        self.window_size, self.stride, self.zscore_per_window = window_size, stride, zscore_per_window
+        self.n_source_channels = (min(s["n_source_channels"] for s in subjects_data) if subjects_data else 0) \
+            if n_source_channels is None else n_source_channels
+        self.n_target_channels = (min(s["n_target_channels"] for s in subjects_data) if subjects_data else 0) \
+            if n_target_channels is None else n_target_channels
+        lengths = [int(s["n_samples"]) for s in subjects_data]
+        self.windows = ecog_windows(lengths, window_size, stride)
+        self.offsets = [0]
+        for s in subjects_data:
+            self.offsets.append(self.offsets[-1] + int(s["source"].shape[1]))
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceRecordings keeps the data in GPU memory; there is no CPU path")
+        cat = lambda key, c: torch.from_numpy(np.ascontiguousarray(
+            np.concatenate([np.asarray(s[key])[:c] for s in subjects_data], axis=1))) if subjects_data else torch.zeros((c, 0))
+        self.source = cat("source", self.n_source_channels).to(self.device)      # ONE upload per recording set
+        self.target = cat("target", self.n_target_channels).to(self.device)
+        if dtype is not None:
+            self.source, self.target = self.source.to(dtype), self.target.to(dtype)
+        starts = [self.offsets[si] + st for si, st in self.windows]
+        for (si, st), a in zip(self.windows, starts):                              # host-side validation: the kernel trusts these
+            if st < 0 or st + window_size > self.offsets[si + 1] - self.offsets[si]:
+                raise ValueError(f"window ({si}, {st}) leaves recording {si}")
+        self._starts = torch.tensor(starts, dtype=torch.int64, device=self.device)
+
+    def __len__(self) -> int:
+        return len(self.windows)
+
+    def _gather(self, rec, idx, out_dtype):
+        import torch
+        from . import _lib
+        from .ops import _dt, _p, _stream
+        c, total = rec.shape
+        out = torch.empty((idx.numel(), c, self.window_size), dtype=out_dtype or rec.dtype, device=self.device)
+        if idx.numel() == 0:
+            return out
+        starts = self._starts.index_select(0, idx)
+        _lib.check(_lib.load().unet_gather_windows(_dt(rec), _dt(out), _p(rec), rec.stride(0), total, _p(starts), idx.numel(), c,
+                                                   self.window_size, int(self.zscore_per_window), 1e-8, _p(out), _stream()),
+                   "unet_gather_windows")
+        return out
+
+    def batch(self, indices, out_dtype=None):
+        """{"source": [B, Cs, W], "target": [B, Ct, W], "subject_idx": [B], "start_sample": [B]} on the device."""
+        import torch
+        idx = torch.as_tensor(indices, dtype=torch.int64)
+        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= len(self.windows)):
+            raise IndexError("window index out of range")
+        meta = torch.tensor([self.windows[i] for i in idx.tolist()], dtype=torch.int64).reshape(-1, 2)
+        idx = idx.to(self.device)
+        return {"source": self._gather(self.source, idx, out_dtype), "target": self._gather(self.target, idx, out_dtype),
+                "subject_idx": meta[:, 0], "start_sample": meta[:, 1]}
