@@ -32,7 +32,7 @@ DEFAULT_CFG = dict(  # models.py:2871-2901 (ctor defaults)
     dropout=0.0, use_attention=True, attention_type="basic", norm_type="batch",
     cond_mode="cross_attn_gated", n_downsample=2, conv_type="standard",
     use_se=True, conv_kernel_size=7, dilations=(1, 4, 16, 32),
-    use_adaptive_scaling=False, activation="relu", skip_type="add",
+    use_adaptive_scaling=False, activation="relu", skip_type="add", n_heads=4,
 )
 
 
@@ -217,6 +217,35 @@ def self_attention(sd: SD, pfx: str, x: Tensor) -> Tensor:
     return x + sd[pfx + "gamma"] * o
 
 
+CFC_BANDS = ((1, 4), (4, 8), (8, 12), (12, 30), (30, 80))   # models.py:262-269
+
+
+def cross_freq_v2(sd: SD, pfx: str, x: Tensor, n_heads: int = 4, sample_rate: float = 1000.0) -> Tensor:
+    """CrossFrequencyCouplingAttentionV2.forward (models.py:342-429): FFT band split (soft sigmoid masks,
+    :293-340), grouped 1x1 q/k/v projections, every query band attends to every key/value band (softmax over all
+    T positions, scale 1/sqrt(head_dim)), outputs mixed by softmax(coupling_weights), 1x1 out_proj, gated residual."""
+    B, C, T = x.shape
+    nb, hd = len(CFC_BANDS), C // n_heads
+    freqs = torch.fft.rfftfreq(T, d=1.0 / sample_rate)
+    filt = torch.stack([torch.sigmoid((freqs - lo) / 2) * torch.sigmoid((hi - freqs) / 2) for lo, hi in CFC_BANDS], 0)
+    xf = torch.fft.rfft(x.float(), dim=-1)
+    bands = torch.fft.irfft((xf.unsqueeze(1) * filt[None, :, None, :]).reshape(B * nb, C, -1), n=T, dim=-1)
+    flat = bands.reshape(B, nb * C, T).to(x.dtype)
+    proj = lambda n: F.conv1d(flat, sd[pfx + n + ".weight"], sd[pfx + n + ".bias"], groups=nb) \
+        .reshape(B, nb, n_heads, hd, T).permute(0, 1, 2, 4, 3)                       # [B, nb, heads, T, hd]
+    Q, K, V = proj("proj_q"), proj("proj_k"), proj("proj_v")
+    coupling = torch.softmax(sd[pfx + "coupling_weights"], dim=-1)
+    outs = []
+    for i in range(nb):
+        acc = 0
+        for j in range(nb):
+            a = torch.softmax(torch.matmul(Q[:, i], K[:, j].transpose(-2, -1)) / math.sqrt(hd), dim=-1)
+            acc = acc + coupling[i, j] * torch.matmul(a, V[:, j])                    # [B, heads, T, hd]
+        outs.append(acc.permute(0, 1, 3, 2).reshape(B, C, T))
+    out = F.conv1d(torch.cat(outs, 1), sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"])
+    return x + sd[pfx + "gate"] * out
+
+
 def adaptive_scale(sd: SD, pfx: str, x: Tensor, raw: Tensor) -> Tensor:
     """models.py:2043-2068 (scalar SessionAdaptiveScaling)."""
     st = torch.cat([raw.mean(dim=-1), raw.std(dim=-1)], dim=-1)
@@ -262,9 +291,12 @@ def forward(sd: SD, cfg: dict, ob: Tensor, odor_ids: Optional[Tensor] = None,
     has_attn = cfg["use_attention"] and cfg["attention_type"] != "none"
     h = act(cfg["activation"], F.conv1d(skips[-1], sd["mid.0.weight"], sd["mid.0.bias"], padding=1))
     if has_attn:
-        if cfg["attention_type"] != "basic":
-            raise NotImplementedError("oracle covers attention_type in {none, basic}")
-        h = self_attention(sd, "mid.2.", h)
+        if cfg["attention_type"] == "basic":
+            h = self_attention(sd, "mid.2.", h)
+        elif cfg["attention_type"] == "cross_freq_v2":
+            h = cross_freq_v2(sd, "mid.2.", h, cfg.get("n_heads", 4), cfg.get("sampling_rate", 1000.0))
+        else:
+            raise NotImplementedError("oracle covers attention_type in {none, basic, cross_freq_v2}")
         j = 3
     else:
         j = 2
@@ -393,7 +425,17 @@ def init_state_dict(cfg: dict, seed: int = 0) -> SD:
     sd["mid.0.weight"] = rnd(cb, cb, 3)
     sd["mid.0.bias"] = rnd(cb, scale=0.1)
     j = 2
-    if has_attn:
+    if has_attn and cfg["attention_type"] == "cross_freq_v2":
+        nb = len(CFC_BANDS)
+        for n in ("proj_q", "proj_k", "proj_v"):
+            sd[f"mid.2.{n}.weight"] = rnd(nb * cb, cb, 1)
+            sd[f"mid.2.{n}.bias"] = rnd(nb * cb, scale=0.1)
+        sd["mid.2.out_proj.weight"] = rnd(cb, nb * cb, 1)
+        sd["mid.2.out_proj.bias"] = rnd(cb, scale=0.1)
+        sd["mid.2.coupling_weights"] = rnd(nb, nb, scale=0.5)
+        sd["mid.2.gate"] = torch.full((1,), 0.3)
+        j = 3
+    elif has_attn:
         sd["mid.2.query.weight"] = rnd(cb // 8, cb, 1)
         sd["mid.2.query.bias"] = rnd(cb // 8, scale=0.1)
         sd["mid.2.key.weight"] = rnd(cb // 8, cb, 1)

@@ -41,6 +41,8 @@ CASES = {
                                  attention_type="none"), 2, 256, "none", (16, 240)),
     "B_modern_crop4096": (dict(in_channels=4, out_channels=4, base=8, emb_dim=16, conv_type="modern",
                                attention_type="none", activation="gelu"), 2, 4096, "ids", (500, 4500)),
+    "std_crossfreq_v2": (dict(in_channels=8, out_channels=8, base=8, emb_dim=16, attention_type="cross_freq_v2"),
+                         2, 256, "ids", (16, 240)),
     "modern_d4_cap": (dict(in_channels=8, out_channels=8, base=4, emb_dim=16, conv_type="modern",
                            attention_type="none", activation="gelu", n_downsample=4), 2, 512, "ids", (16, 496)),
 }
@@ -52,7 +54,10 @@ def main():
 
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
     for name, (kw, B, T, cond, (lo, hi)) in CASES.items():
+        if only and name not in only:
+            continue
         torch.manual_seed(1234)
         model = ref.CondUNet1D(**kw)
         with torch.no_grad():
@@ -63,6 +68,9 @@ def main():
             for m in model.modules():
                 if isinstance(m, ref.SelfAttention1D):
                     m.gamma.fill_(0.5)
+                if isinstance(m, ref.CrossFrequencyCouplingAttentionV2):
+                    m.gate.fill_(0.5)
+                    m.coupling_weights.normal_(0, 0.5)
                 if isinstance(m, torch.nn.BatchNorm1d):
                     m.running_mean.normal_(0, 0.1)
                     m.running_var.uniform_(0.8, 1.2)

@@ -108,7 +108,8 @@ def test_fp32_eval_matches_reference(name):
 #   same weights.  (The L1 loss of the fixtures has gradient sign(pred - target): a bf16-sized change
 #   of pred flips a fraction f of the signs, which alone moves the gradient by 2*sqrt(f) -- that is a
 #   property of L1 in reduced precision, not of the kernels, so it is not what this test measures.)
-@pytest.mark.parametrize("name", ["A_std_attn_add_bn", "B_modern_add_bn_gelu", "B2_modern_concat", "B_modern_crop4096"])
+@pytest.mark.parametrize("name", ["A_std_attn_add_bn", "B_modern_add_bn_gelu", "B2_modern_concat", "B_modern_crop4096",
+                                  "std_crossfreq_v2"])
 def test_bf16_train_step_close_to_reference(name):
     from oracle import condunet_oracle as O
     g = Golden(name)
@@ -128,8 +129,11 @@ def test_bf16_train_step_close_to_reference(name):
     run_sd.update(leaves)
     ref = O.forward(run_sd, g.cfg, g.t("ob"), training=True, **g.cond_kwargs())
     (ref * G).sum().backward()
+    # the cross-frequency attention adds bf16 roundings of the band signals, q/k/v and 25 attention outputs at
+    # head_dim 8 in this fixture (its own v-projection sees 25 bf16 attention backward passes): a 2e-1 bar
     _check_bf16_grads({k: p.grad for k, p in model.named_parameters()},
-                      {k: v.grad for k, v in leaves.items() if v.grad is not None}, 1e-1)
+                      {k: v.grad for k, v in leaves.items() if v.grad is not None},
+                      2e-1 if g.cfg.get("attention_type") == "cross_freq_v2" else 1e-1)
 
 
 def test_config_b_shape_vs_oracle():

@@ -18,6 +18,7 @@ Out-of-scope constructor options raise ``NotImplementedError`` (never a silent f
 """
 from __future__ import annotations
 
+import math
 from typing import List, Optional, Tuple, Union
 
 import torch
@@ -151,6 +152,95 @@ class SelfAttention1D(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         return _as_ncl(self.forward_nlc(_to_nlc(x)))
+
+
+class CrossFrequencyCouplingAttentionV2(nn.Module):
+    """models.py:227-474 (``attention_type="cross_freq_v2"``, the phase-four / phase-five default): FFT band split,
+    grouped 1x1 q/k/v projections per band, every query band attends to every key/value band, outputs mixed by
+    softmax(coupling_weights), 1x1 out_proj, gated residual.  Same parameters / state-dict keys as the reference.
+
+    Channels-last throughout: the band split is an rFFT along the row axis of the ``[N, L, C]`` tensor (rocFFT,
+    no transposes), the per-band projections and out_proj run on the HIP conv kernels (the grouped Conv1d is five
+    independent C x C convs on strided views of one buffer), the 25 attention products go through
+    ``scaled_dot_product_attention``.  A hand-written MFMA flash kernel for these products (head_dim = C/4 = 256 at
+    config B, 107 GFLOP per window) is the open item of this row; everything around them is on the HIP path.
+    """
+
+    def __init__(self, channels: int, n_heads: int = 4, sample_rate: float = 1000.0, bands=None, chunk_size: int = 256,
+                 enable_flash: bool = True):
+        super().__init__()
+        self.channels = channels
+        self.n_heads = n_heads
+        self.head_dim = channels // n_heads
+        self.sample_rate = sample_rate
+        self.enable_flash = enable_flash
+        self.chunk_size = chunk_size
+        if bands is None:
+            bands = [(1, 4), (4, 8), (8, 12), (12, 30), (30, 80)]
+        self.bands = bands
+        self.n_bands = len(bands)
+        nb = self.n_bands
+        self.proj_q = nn.Conv1d(channels * nb, channels * nb, 1, groups=nb)
+        self.proj_k = nn.Conv1d(channels * nb, channels * nb, 1, groups=nb)
+        self.proj_v = nn.Conv1d(channels * nb, channels * nb, 1, groups=nb)
+        self.out_proj = nn.Conv1d(channels * nb, channels, 1)
+        self.coupling_weights = nn.Parameter(torch.ones(nb, nb) / nb)
+        self.gate = nn.Parameter(torch.zeros(1))
+        self._filters_cache: Optional[Tensor] = None
+        self._cache_len: int = 0
+        self._filters_on = {}
+        self.scale = 1.0 / math.sqrt(self.head_dim)
+
+    def _build_bandpass_filters_batched(self, T: int, device) -> Tensor:
+        """models.py:293-312; the device copy is cached (no host transfer per step)."""
+        freq_len = T // 2 + 1
+        if self._filters_cache is None or self._cache_len != freq_len:
+            freqs = torch.fft.rfftfreq(T, d=1.0 / self.sample_rate)
+            self._filters_cache = torch.stack([torch.sigmoid((freqs - lo) / 2) * torch.sigmoid((hi - freqs) / 2)
+                                               for lo, hi in self.bands], dim=0)
+            self._cache_len = freq_len
+            self._filters_on = {}
+        key = str(torch.device(device))
+        if key not in self._filters_on:
+            self._filters_on[key] = self._filters_cache.to(device)
+        return self._filters_on[key]
+
+    def forward_nlc(self, x: Tensor) -> Tensor:
+        n, t, c = x.shape
+        nb, nh, hd = self.n_bands, self.n_heads, self.head_dim
+        filt = self._build_bandpass_filters_batched(t, x.device)                       # [nb, F]
+        xf = torch.fft.rfft(x.float(), dim=1)                                          # [N, F, C]
+        bands = torch.fft.irfft(xf.unsqueeze(1) * filt[None, :, :, None], n=t, dim=2)  # [N, nb, L, C]
+        bands = bands.to(x.dtype)
+        g1 = ops.geom_conv(1)
+
+        def project(conv):
+            w = conv.weight.view(nb, c, c, 1)
+            b = conv.bias.view(nb, c)
+            # band i: its own C x C conv on the strided view bands[:, i]; -> [N, heads, L, hd]
+            return [ops.conv(bands[:, i], w[i].permute(2, 0, 1), b[i], g1, t).view(n, t, nh, hd).transpose(1, 2)
+                    for i in range(nb)]
+
+        q, k, v = project(self.proj_q), project(self.proj_k), project(self.proj_v)
+        coupling = F.softmax(self.coupling_weights.float(), dim=-1)
+        outs = []
+        for i in range(nb):
+            acc = None
+            for j in range(nb):
+                a = F.scaled_dot_product_attention(q[i], k[j], v[j], dropout_p=0.0, is_causal=False)
+                a = a.float() * coupling[i, j]
+                acc = a if acc is None else acc + a
+            outs.append(acc.transpose(1, 2).reshape(n, t, c))                          # channel = head * hd + d
+        cat = torch.cat(outs, dim=2).to(x.dtype)                                       # [N, L, nb*C]
+        out = ops.conv(cat, self.out_proj.weight.permute(2, 0, 1), self.out_proj.bias, g1, t)
+        return (x.float() + self.gate.float() * out.float()).to(x.dtype)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return _as_ncl(self.forward_nlc(_to_nlc(x)))
+
+    def extra_repr(self) -> str:
+        band_str = ", ".join(f"{l}-{h}Hz" for l, h in self.bands)
+        return f"channels={self.channels}, n_heads={self.n_heads}, flash={self.enable_flash}, bands=[{band_str}]"
 
 
 class FiLM(nn.Module):
@@ -592,8 +682,11 @@ class CondUNet1D(nn.Module):
     def _build_attention(self, channels: int, attention_type: str) -> nn.Module:
         if attention_type == "basic":
             return SelfAttention1D(channels)
-        if attention_type in ("cross_freq", "cross_freq_v2"):
-            raise NotImplementedError(f"attention_type={attention_type!r} is a 'next' row (SURVEY.md 8f N3), not built yet")
+        if attention_type == "cross_freq_v2":
+            return CrossFrequencyCouplingAttentionV2(channels, n_heads=self.n_heads)
+        if attention_type == "cross_freq":
+            raise NotImplementedError("attention_type='cross_freq' (the chunked V1 module) is not built; "
+                                      "'cross_freq_v2' is (SURVEY.md 8f N3)")
         raise ValueError(f"Unknown attention_type: {attention_type}. Available: none, basic, cross_freq, cross_freq_v2")
 
     def set_gradient_checkpointing(self, enable: bool = True):
