@@ -93,7 +93,7 @@ class BucketedGradAllReduce:
                 if p.grad is None:
                     v.zero_()  # parameter unused this step: contributes zeros (find_unused_parameters semantics)
                 p.grad = v
-        if self.average and flat.is_cuda:
+        if self.average and _has_avg(self.pg):
             h = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
             self._handles.append((h, None))
         else:  # gloo has no AVG
@@ -115,6 +115,11 @@ class BucketedGradAllReduce:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+def _has_avg(process_group=None) -> bool:
+    """ReduceOp.AVG exists in RCCL (backend "nccl") only; gloo gets SUM followed by a division."""
+    return str(dist.get_backend(process_group)).lower() == "nccl"
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=None):

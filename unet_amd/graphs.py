@@ -20,6 +20,8 @@ from typing import Callable, List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
+from .dp import _has_avg
+
 
 class GraphedTrainStep:
     """Capture ``loss = loss_fn(model(*inputs), *targets); loss.backward(); clip; optimizer.step()``.
@@ -123,7 +125,7 @@ class GraphedTrainStep:
                     v.zero_()
         handles = []
         for flat in self._flat:
-            if flat.is_cuda:
+            if _has_avg(self.pg):
                 handles.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True), None))
             else:
                 handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), flat))
