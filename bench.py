@@ -42,7 +42,7 @@ CROP = (500, 4500)
 GFLOP_PER_WINDOW_FWD = 122.339       # algorithmic conv FLOPs, config B
 BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 KERNEL_DESCR = {
-    "conv_fwd2_kernel": "conv_fwd2_kernel_128 (bf16 implicit-GEMM tap-list conv, forward and data-grad launches)",
+    "conv_fwd2_kernel": "conv_fwd2_kernel_128/_192 (bf16 implicit-GEMM tap-list conv, forward and data-grad launches)",
     "conv_stream_kernel": "conv_stream_kernel (bf16 single-tap conv, persistent 256x128 tiles)",
     "conv_wgrad2_kernel": "conv_wgrad2_kernel (bf16 weight-grad, two taps per block, split-K slabs)",
     "conv_fwd_kernel": "conv_fwd_kernel (generic / fp32 implicit-GEMM conv)",
