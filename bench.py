@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--conditioning", default="odor_onehot", choices=["odor_onehot", "spectro_temporal"],
                     help="spectro_temporal: the SpectroTemporalEncoder (train.py --conditioning default) runs inside the "
                          "step and trains with the model; the headline config is odor_onehot")
+    ap.add_argument("--graph", action="store_true", help="replay the captured HIP graph also for N > 1 (all-reduce runs "
+                    "between the two graphs, not overlapped); default for N > 1 is the eager hook-driven path")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one (hook-driven overlapped "
                     "all-reduce) instead of replaying the captured HIP graph")
     return ap.parse_args()
@@ -94,6 +96,11 @@ def cpu_baseline(n_windows: int):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # N > 1: kernels are launched one by one so that each gradient bucket's RCCL all-reduce starts from its autograd
+    # hook and overlaps the rest of backward (the host enqueues a step in ~18 ms, the GPU needs ~28 ms, so the
+    # launches stay ahead); the captured graph has no such overlap (fwd+bwd graph -> all-reduce -> update graph).
+    if world > 1 and not args.graph:
+        args.eager = True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
