@@ -127,8 +127,10 @@ __device__ __forceinline__ float act_fwd(int act, float x) {
     case UNET_ACT_GELU: { float c, e; gelu_cdf(x, c, e); return x * c; }
     case UNET_ACT_SILU: return x / (1.f + __expf(-x));
     case UNET_ACT_MISH: {
-      float sp = x > 20.f ? x : log1pf(__expf(x));
-      return x * tanhf(sp);
+      // x * tanh(softplus(x)); with e = exp(x): tanh(log(1 + e)) = e(e + 2) / (e(e + 2) + 2)  (one exp, one divide)
+      if (x > 20.f) return x;
+      const float e = __expf(x), n = e * (e + 2.f);
+      return x * (n / (n + 2.f));
     }
     default: return x;
   }
@@ -143,9 +145,10 @@ __device__ __forceinline__ float act_bwd(int act, float x) {
       return s * (1.f + x * (1.f - s));
     }
     case UNET_ACT_MISH: {
-      float sp = x > 20.f ? x : log1pf(__expf(x));
-      float t = tanhf(sp);
-      float s = 1.f / (1.f + __expf(-x));
+      if (x > 20.f) return 1.f;
+      const float e = __expf(x), n = e * (e + 2.f);
+      const float t = n / (n + 2.f);             // tanh(softplus(x))
+      const float s = e / (1.f + e);             // sigmoid(x)
       return t + x * (1.f - t * t) * s;
     }
     default: return 1.f;

@@ -10,7 +10,13 @@
 
 namespace {
 
-constexpr int ROWS_PER_PART = 128;
+// Rows per workgroup: 1/32 of the window (at most 128, at least 16, a multiple of 8), so that short, wide tensors
+// (1024 rows x 1024 channels at the bottleneck) still launch 32 x N workgroups -- with a fixed 128 rows they launched
+// 8 x N and ran at 3.4 TB/s instead of 5+.  Host (partial-buffer sizes, unet_parts) and kernels use the same rule.
+__host__ __device__ inline int rows_per_part(int rows) {
+  int r = ((rows + 31) / 32 + 7) & ~7;
+  return r < 16 ? 16 : (r > 128 ? 128 : r);
+}
 constexpr int THREADS = 256;
 
 template <class OP>
@@ -23,8 +29,9 @@ __global__ __launch_bounds__(THREADS) void rowstream_kernel(OP op, int rows, int
   const int cvb = cv < THREADS ? cv : THREADS;
   const int RL = THREADS / cvb;
   const int rl = tid / cvb, cgl = tid - rl * cvb;
-  const int r_begin = part * ROWS_PER_PART;
-  const int r_end = rows < r_begin + ROWS_PER_PART ? rows : r_begin + ROWS_PER_PART;
+  const int rpp = rows_per_part(rows);
+  const int r_begin = part * rpp;
+  const int r_end = rows < r_begin + rpp ? rows : r_begin + rpp;
   for (int cb = 0; cb < cv; cb += cvb) {
     const int cg = cb + cgl;
     const bool active = rl < RL && cg < cv;
@@ -227,7 +234,7 @@ template <typename T, int V_> struct GatedAddBwdOp : OpBase<T, V_> {
 
 template <class OP>
 int launch_rows(const OP& op, int n, int rows, int c, hipStream_t st, const char* what) {
-  const int parts = cdiv(rows, ROWS_PER_PART);
+  const int parts = cdiv(rows, rows_per_part(rows));
   hipLaunchKernelGGL(rowstream_kernel<OP>, dim3(parts, n), dim3(THREADS), 0, st, op, rows, c, parts);
   UNET_LAUNCH_CHECK(what);
   return 0;
@@ -282,8 +289,9 @@ __global__ __launch_bounds__(THREADS) void film_softmax_fwd_kernel(const T* q, c
       v[i][e] = cg < cv ? vv[(long long)n * c + cg * V + e] : 0.f;
     }
   }
-  const int r_begin = part * ROWS_PER_PART;
-  const int r_end = rows < r_begin + ROWS_PER_PART ? rows : r_begin + ROWS_PER_PART;
+  const int rpp = rows_per_part(rows);
+  const int r_begin = part * rpp;
+  const int r_end = rows < r_begin + rpp ? rows : r_begin + rpp;
   for (int r = r_begin + wave; r < r_end; r += THREADS / 64) {
     const long long base = ((long long)n * rows + r) * c;
     float s[NV][V];
@@ -339,8 +347,9 @@ __global__ __launch_bounds__(THREADS) void film_softmax_bwd_kernel(const T* q, c
       akk[i][e] = 0.f; av[i][e] = 0.f;
     }
   }
-  const int r_begin = part * ROWS_PER_PART;
-  const int r_end = rows < r_begin + ROWS_PER_PART ? rows : r_begin + ROWS_PER_PART;
+  const int rpp = rows_per_part(rows);
+  const int r_begin = part * rpp;
+  const int r_end = rows < r_begin + rpp ? rows : r_begin + rpp;
   for (int r = r_begin + wave; r < r_end; r += THREADS / 64) {
     const long long base = ((long long)n * rows + r) * c;
     float s[NV][V], qv[NV][V], g[NV][V];
@@ -572,7 +581,7 @@ int film_dispatch(bool bwd, const void* q, const void* dh, const float* kk, cons
                   float* dkk, float* dv, int n, int rows, int c, hipStream_t st) {
   const int cv = c / V;
   const int nv = cdiv(cv, 64);
-  const int parts = cdiv(rows, ROWS_PER_PART);
+  const int parts = cdiv(rows, rows_per_part(rows));
   dim3 grid(parts, n), blk(THREADS);
 #define FILM_CASE(NVV)                                                                                  \
   if (nv <= NVV) {                                                                                      \
@@ -710,7 +719,7 @@ int transpose_out(int out_dtype, const void* x, const void* x2, void* y, const f
 
 }  // namespace
 
-extern "C" int32_t unet_parts(int32_t rows) { return cdiv(rows, ROWS_PER_PART); }
+extern "C" int32_t unet_parts(int32_t rows) { return cdiv(rows, rows_per_part(rows)); }
 
 extern "C" int unet_rowstats(int32_t dtype, const void* y, float* s1_part, float* s2_part, int32_t n,
                              int32_t rows, int32_t c, void* stream) {
