@@ -170,15 +170,18 @@ int unet_scale_bwd(int32_t dtype, const void* x, const void* dout, const float* 
 /* FiLM channel softmax (models.py:514-515): h[n,t,:] = softmax_c(q[n,t,:]*kk[n,:]) * v[n,:] */
 int unet_film_softmax_fwd(int32_t dtype, const void* q, const float* kk, const float* v, void* h,
                           int32_t n, int32_t rows, int32_t c, void* stream);
+/* dq_sum_part (nullable): partial column sums of dq = the bias gradient of q_proj, taken in the same pass for
+ * rows of up to 512 channels (a second pass over dq beyond that) */
 int unet_film_softmax_bwd(int32_t dtype, const void* q, const void* dh, const float* kk,
-                          const float* v, void* dq, float* dkk_part, float* dv_part, int32_t n,
-                          int32_t rows, int32_t c, void* stream);
+                          const float* v, void* dq, float* dkk_part, float* dv_part, float* dq_sum_part,
+                          int32_t n, int32_t rows, int32_t c, void* stream);
 
-/* out = res + g[n][c]*o  (models.py:517);  bwd: do = g*dout, dg_part = sum_t dout*o */
+/* out = res + g[n][c]*o  (models.py:517);  bwd: do = g*dout, dg_part = sum_t dout*o; do_sum_part (nullable):
+ * partial column sums of do = the bias gradient of out_proj, taken in the same pass */
 int unet_gated_add_fwd(int32_t dtype, const void* res, const void* o, const float* g, void* out,
                        int32_t n, int32_t rows, int32_t c, void* stream);
 int unet_gated_add_bwd(int32_t dtype, const void* o, const void* dout, const float* g, void* d_o,
-                       float* dg_part, int32_t n, int32_t rows, int32_t c, void* stream);
+                       float* dg_part, float* do_sum_part, int32_t n, int32_t rows, int32_t c, void* stream);
 
 /* column sums over all rows of all windows: out_part[n][parts][c] = partial sum_t x  (bias grads) */
 int unet_colsum(int32_t dtype, const void* x, float* out_part, int32_t n, int32_t rows, int32_t c,

@@ -62,9 +62,9 @@ _SIGNATURES = {
     "unet_scale_fwd": (C.c_int, [_i32, _vp, _vp, _vp] + _row_args),
     "unet_scale_bwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp] + _row_args),
     "unet_film_softmax_fwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp] + _row_args),
-    "unet_film_softmax_bwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + _row_args),
+    "unet_film_softmax_bwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + _row_args),
     "unet_gated_add_fwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp] + _row_args),
-    "unet_gated_add_bwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp] + _row_args),
+    "unet_gated_add_bwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp] + _row_args),
     "unet_merge_taps_parts": (_i32, [_i32, _i32]),
     "unet_merge_taps_fwd": (C.c_int, [C.POINTER(_vp), _vp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _vp, _vp]),
     "unet_merge_taps_bwd": (C.c_int, [C.POINTER(_vp), _vp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _vp,

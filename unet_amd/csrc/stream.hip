@@ -216,20 +216,28 @@ template <typename T, int V_> struct GatedAddFwdOp : OpBase<T, V_> {
   }
   __device__ void write_part(long long, const float (&)[1][V_]) const {}
 };
-template <typename T, int V_> struct GatedAddBwdOp : OpBase<T, V_> {
-  static constexpr int NRED = 1;
-  const T* o; const T* dout; T* d_o; const float* g; float* dg;
+// SUM: also the per-part column sums of d_o (the bias gradient of the conv that produced o), saving a pass over d_o
+template <typename T, int V_, bool SUM> struct GatedAddBwdOp : OpBase<T, V_> {
+  static constexpr int NRED = SUM ? 2 : 1;
+  const T* o; const T* dout; T* d_o; const float* g; float* dg; float* dsum;
   struct State { float g[V_]; };
   __device__ void init(State& st, int n, int c0, int c) const { this->ldc(g + (long long)n * c + c0, st.g); }
-  __device__ void row(State& st, long long e, float (&acc)[1][V_]) const {
+  __device__ void row(State& st, long long e, float (&acc)[SUM ? 2 : 1][V_]) const {
     float fo[V_], fd[V_];
     VecIO<T, V_>::load(o + e, fo);
     VecIO<T, V_>::load(dout + e, fd);
 #pragma unroll
-    for (int i = 0; i < V_; ++i) { acc[0][i] += fd[i] * fo[i]; fd[i] *= st.g[i]; }
+    for (int i = 0; i < V_; ++i) {
+      acc[0][i] += fd[i] * fo[i];
+      fd[i] *= st.g[i];
+      if (SUM) acc[SUM ? 1 : 0][i] += fd[i];
+    }
     VecIO<T, V_>::store(d_o + e, fd);
   }
-  __device__ void write_part(long long e, const float (&sm)[1][V_]) const { this->stc(dg + e, sm[0]); }
+  __device__ void write_part(long long e, const float (&sm)[SUM ? 2 : 1][V_]) const {
+    this->stc(dg + e, sm[0]);
+    if (SUM) this->stc(dsum + e, sm[SUM ? 1 : 0]);
+  }
 };
 
 template <class OP>
@@ -329,14 +337,16 @@ __global__ __launch_bounds__(THREADS) void film_softmax_fwd_kernel(const T* q, c
   }
 }
 
-template <typename T, int V, int NV>
+// SUM: also the per-part column sums of dq (the bias gradient of q_proj) -- one more accumulator per channel
+template <typename T, int V, int NV, bool SUM>
 __global__ __launch_bounds__(THREADS) void film_softmax_bwd_kernel(const T* q, const T* dh, const float* kk,
                                                                     const float* vv, T* dq, float* dkk_part,
-                                                                    float* dv_part, int rows, int c, int parts) {
-  __shared__ float red_s[2][THREADS / 64][64 * NV * V];
+                                                                    float* dv_part, float* dq_sum_part, int rows, int c,
+                                                                    int parts) {
+  __shared__ float red_s[SUM ? 3 : 2][THREADS / 64][64 * NV * V];
   const int n = blockIdx.y, part = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cv = c / V;
-  float k[NV][V], v[NV][V], akk[NV][V], av[NV][V];
+  float k[NV][V], v[NV][V], akk[NV][V], av[NV][V], adq[SUM ? NV : 1][V];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int cg = lane + 64 * i;
@@ -345,6 +355,7 @@ __global__ __launch_bounds__(THREADS) void film_softmax_bwd_kernel(const T* q, c
       k[i][e] = cg < cv ? kk[(long long)n * c + cg * V + e] : 0.f;
       v[i][e] = cg < cv ? vv[(long long)n * c + cg * V + e] : 0.f;
       akk[i][e] = 0.f; av[i][e] = 0.f;
+      if (SUM) adq[SUM ? i : 0][e] = 0.f;
     }
   }
   const int rpp = rows_per_part(rows);
@@ -400,6 +411,7 @@ __global__ __launch_bounds__(THREADS) void film_softmax_bwd_kernel(const T* q, c
           const float ds = s[i][e] * (g[i][e] - dot);  // d(q*kk)
           akk[i][e] += ds * qv[i][e];
           g[i][e] = ds * k[i][e];
+          if (SUM) adq[SUM ? i : 0][e] += g[i][e];
         }
         VecIO<T, V>::store(dq + base + cg * V, g[i]);
       }
@@ -411,6 +423,7 @@ __global__ __launch_bounds__(THREADS) void film_softmax_bwd_kernel(const T* q, c
     for (int e = 0; e < V; ++e) {
       red_s[0][wave][(i * V + e) * 64 + lane] = akk[i][e];
       red_s[1][wave][(i * V + e) * 64 + lane] = av[i][e];
+      if (SUM) red_s[SUM ? 2 : 0][wave][(i * V + e) * 64 + lane] = adq[SUM ? i : 0][e];
     }
   __syncthreads();
   if (wave == 0) {
@@ -420,13 +433,15 @@ __global__ __launch_bounds__(THREADS) void film_softmax_bwd_kernel(const T* q, c
       if (cg < cv) {
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          float a0 = 0.f, a1 = 0.f;
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f;
           for (int w = 0; w < THREADS / 64; ++w) {
             a0 += red_s[0][w][(i * V + e) * 64 + lane];
             a1 += red_s[1][w][(i * V + e) * 64 + lane];
+            if (SUM) a2 += red_s[SUM ? 2 : 0][w][(i * V + e) * 64 + lane];
           }
           const long long o = ((long long)n * parts + part) * c + cg * V + e;
           dkk_part[o] = a0; dv_part[o] = a1;
+          if (SUM) dq_sum_part[o] = a2;
         }
       }
     }
@@ -578,16 +593,21 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* in, int 
 
 template <typename T, int V>
 int film_dispatch(bool bwd, const void* q, const void* dh, const float* kk, const float* v, void* out,
-                  float* dkk, float* dv, int n, int rows, int c, hipStream_t st) {
+                  float* dkk, float* dv, float* dqs, bool* fused, int n, int rows, int c, hipStream_t st) {
   const int cv = c / V;
   const int nv = cdiv(cv, 64);
   const int parts = cdiv(rows, rows_per_part(rows));
   dim3 grid(parts, n), blk(THREADS);
 #define FILM_CASE(NVV)                                                                                  \
   if (nv <= NVV) {                                                                                      \
-    if (bwd)                                                                                            \
-      hipLaunchKernelGGL((film_softmax_bwd_kernel<T, V, NVV>), grid, blk, 0, st, (const T*)q, (const T*)dh, kk, \
-                         v, (T*)out, dkk, dv, rows, c, parts);                                          \
+    if (bwd && dqs && NVV <= 2) {                                                                       \
+      if constexpr (NVV <= 2)                                                                           \
+        hipLaunchKernelGGL((film_softmax_bwd_kernel<T, V, NVV, true>), grid, blk, 0, st, (const T*)q, (const T*)dh, kk, \
+                           v, (T*)out, dkk, dv, dqs, rows, c, parts);                                   \
+      *fused = true;                                                                                    \
+    } else if (bwd)                                                                                       \
+      hipLaunchKernelGGL((film_softmax_bwd_kernel<T, V, NVV, false>), grid, blk, 0, st, (const T*)q, (const T*)dh, kk, \
+                         v, (T*)out, dkk, dv, nullptr, rows, c, parts);                                 \
     else                                                                                                \
       hipLaunchKernelGGL((film_softmax_fwd_kernel<T, V, NVV>), grid, blk, 0, st, (const T*)q, kk, v, (T*)out, rows, c); \
     UNET_LAUNCH_CHECK("film_softmax");                                                                  \
@@ -601,22 +621,27 @@ int film_dispatch(bool bwd, const void* q, const void* dh, const float* kk, cons
 }
 
 int film_entry(bool bwd, int dtype, const void* q, const void* dh, const float* kk, const float* v, void* out,
-               float* dkk, float* dv, int n, int rows, int c, void* stream) {
+               float* dkk, float* dv, float* dqs, int n, int rows, int c, void* stream) {
   if (check_dims(n, rows, c, "film_softmax")) return -1;
   UNET_REQUIRE(q && kk && v && out && (!bwd || (dh && dkk && dv)), "film_softmax: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  bool fused = false;
+  int rc = -2;
   if (dtype == UNET_F32) {
     const bool vec = c % 4 == 0 && aligned16(q) && aligned16(out) && (!dh || aligned16(dh));
-    return vec ? film_dispatch<float, 4>(bwd, q, dh, kk, v, out, dkk, dv, n, rows, c, st)
-               : film_dispatch<float, 1>(bwd, q, dh, kk, v, out, dkk, dv, n, rows, c, st);
-  }
-  if (dtype == UNET_BF16) {
+    rc = vec ? film_dispatch<float, 4>(bwd, q, dh, kk, v, out, dkk, dv, dqs, &fused, n, rows, c, st)
+               : film_dispatch<float, 1>(bwd, q, dh, kk, v, out, dkk, dv, dqs, &fused, n, rows, c, st);
+  } else if (dtype == UNET_BF16) {
     const bool vec = c % 4 == 0 && ((uintptr_t)q % 8 == 0) && ((uintptr_t)out % 8 == 0) && (!dh || (uintptr_t)dh % 8 == 0);
-    return vec ? film_dispatch<__bf16, 4>(bwd, q, dh, kk, v, out, dkk, dv, n, rows, c, st)
-               : film_dispatch<__bf16, 1>(bwd, q, dh, kk, v, out, dkk, dv, n, rows, c, st);
+    rc = vec ? film_dispatch<__bf16, 4>(bwd, q, dh, kk, v, out, dkk, dv, dqs, &fused, n, rows, c, st)
+             : film_dispatch<__bf16, 1>(bwd, q, dh, kk, v, out, dkk, dv, dqs, &fused, n, rows, c, st);
+  } else {
+    unet_set_error("film_softmax: bad dtype %d", dtype);
+    return -1;
   }
-  unet_set_error("film_softmax: bad dtype %d", dtype);
-  return -1;
+  if (rc == 0 && bwd && dqs && !fused)   // wide rows: the kernel has no registers to spare for it; separate pass over dq
+    return unet_colsum(dtype, out, dqs, n, rows, c, stream);
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -830,12 +855,18 @@ extern "C" int unet_gated_add_fwd(int32_t dtype, const void* res, const void* o,
 }
 
 extern "C" int unet_gated_add_bwd(int32_t dtype, const void* o, const void* dout, const float* g, void* d_o,
-                                  float* dg_part, int32_t n, int32_t rows, int32_t c, void* stream) {
+                                  float* dg_part, float* do_sum_part, int32_t n, int32_t rows, int32_t c, void* stream) {
   if (check_dims(n, rows, c, "gated_add_bwd")) return -1;
   UNET_REQUIRE(o && dout && g && d_o && dg_part, "gated_add_bwd: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH_ROWS(dtype, c, PL(o, dout, d_o), {
-    GatedAddBwdOp<T, V> op; op.o = (const T*)o; op.dout = (const T*)dout; op.d_o = (T*)d_o; op.g = g; op.dg = dg_part;
+    if (do_sum_part) {
+      GatedAddBwdOp<T, V, true> op; op.o = (const T*)o; op.dout = (const T*)dout; op.d_o = (T*)d_o; op.g = g;
+      op.dg = dg_part; op.dsum = do_sum_part;
+      return launch_rows(op, n, rows, c, st, "gated_add_bwd");
+    }
+    GatedAddBwdOp<T, V, false> op; op.o = (const T*)o; op.dout = (const T*)dout; op.d_o = (T*)d_o; op.g = g;
+    op.dg = dg_part; op.dsum = nullptr;
     return launch_rows(op, n, rows, c, st, "gated_add_bwd");
   });
   return 0;
@@ -843,12 +874,12 @@ extern "C" int unet_gated_add_bwd(int32_t dtype, const void* o, const void* dout
 
 extern "C" int unet_film_softmax_fwd(int32_t dtype, const void* q, const float* kk, const float* v, void* h,
                                      int32_t n, int32_t rows, int32_t c, void* stream) {
-  return film_entry(false, dtype, q, nullptr, kk, v, h, nullptr, nullptr, n, rows, c, stream);
+  return film_entry(false, dtype, q, nullptr, kk, v, h, nullptr, nullptr, nullptr, n, rows, c, stream);
 }
 extern "C" int unet_film_softmax_bwd(int32_t dtype, const void* q, const void* dh, const float* kk,
-                                     const float* v, void* dq, float* dkk_part, float* dv_part, int32_t n,
-                                     int32_t rows, int32_t c, void* stream) {
-  return film_entry(true, dtype, q, dh, kk, v, dq, dkk_part, dv_part, n, rows, c, stream);
+                                     const float* v, void* dq, float* dkk_part, float* dv_part, float* dq_sum_part,
+                                     int32_t n, int32_t rows, int32_t c, void* stream) {
+  return film_entry(true, dtype, q, dh, kk, v, dq, dkk_part, dv_part, dq_sum_part, n, rows, c, stream);
 }
 
 extern "C" int unet_ncl_moments(int32_t in_dtype, const void* x, float* mean, float* rstd, int32_t n, int32_t c,

@@ -379,6 +379,14 @@ def colsum(x: Tensor) -> Tensor:
     return out
 
 
+def _reduce_all_parts(buf: Tensor) -> Tensor:
+    """[N, parts, C] partial column sums -> [C] (second stage of colsum)"""
+    c = buf.shape[2]
+    out = torch.empty(c, dtype=torch.float32, device=buf.device)
+    check(_lib.load().unet_reduce_rows(_p(buf), buf.shape[0] * buf.shape[1], c, _p(out), _stream()), "unet_reduce_rows")
+    return out
+
+
 _CONST_CACHE = {}
 
 
@@ -599,7 +607,7 @@ class FilmSoftmaxFn(torch.autograd.Function):
         dh = dh.contiguous()
         dq = torch.empty_like(q)
         dkp, dvp = _part_buf(q, 2)
-        check(lib.unet_film_softmax_bwd(_dt(q), _p(q), _p(dh), _p(kf), _p(vf), _p(dq), _p(dkp), _p(dvp), *_dims(q),
+        check(lib.unet_film_softmax_bwd(_dt(q), _p(q), _p(dh), _p(kf), _p(vf), _p(dq), _p(dkp), _p(dvp), _p(None), *_dims(q),
                                         _stream()), "unet_film_softmax_bwd")
         return dq, sum_parts(dkp).to(ctx.kdt), sum_parts(dvp).to(ctx.vdt)
 
@@ -627,7 +635,7 @@ class GatedAddFn(torch.autograd.Function):
         dout = dout.contiguous()
         d_o = torch.empty_like(o)
         (dgp,) = _part_buf(o)
-        check(lib.unet_gated_add_bwd(_dt(o), _p(o), _p(dout), _p(gf), _p(d_o), _p(dgp), *_dims(o), _stream()),
+        check(lib.unet_gated_add_bwd(_dt(o), _p(o), _p(dout), _p(gf), _p(d_o), _p(dgp), _p(None), *_dims(o), _stream()),
               "unet_gated_add_bwd")
         return dout, d_o, sum_parts(dgp).to(ctx.gdt)
 
@@ -670,17 +678,18 @@ class FilmFn(torch.autograd.Function):
         n, rows, c = z.shape
         g1 = geom_conv(1)
         d_o = torch.empty_like(o)
-        (dgp,) = _part_buf(o)
-        check(lib.unet_gated_add_bwd(dt, _p(o), _p(dout), _p(gf), _p(d_o), _p(dgp), n, rows, c, st), "unet_gated_add_bwd")
+        dgp, dop = _part_buf(o, 2)
+        check(lib.unet_gated_add_bwd(dt, _p(o), _p(dout), _p(gf), _p(d_o), _p(dgp), _p(dop), n, rows, c, st),
+              "unet_gated_add_bwd")
         dwo = conv_wgrad_raw(g1, h, None, d_o, c)
-        dbo = colsum(d_o)
+        dbo = _reduce_all_parts(dop)                      # bias gradient of out_proj from the same pass
         dh = conv_dgrad_raw(g1, wof, d_o, rows, 0, c)
         dq = torch.empty_like(q)
-        dkp, dvp = _part_buf(q, 2)
-        check(lib.unet_film_softmax_bwd(dt, _p(q), _p(dh), _p(kf), _p(vf), _p(dq), _p(dkp), _p(dvp), n, rows, c, st),
-              "unet_film_softmax_bwd")
+        dkp, dvp, dqp = _part_buf(q, 3)
+        check(lib.unet_film_softmax_bwd(dt, _p(q), _p(dh), _p(kf), _p(vf), _p(dq), _p(dkp), _p(dvp), _p(dqp), n, rows, c,
+                                        st), "unet_film_softmax_bwd")
         dwq = conv_wgrad_raw(g1, z, None, dq, c)
-        dbq = colsum(dq)
+        dbq = _reduce_all_parts(dqp)                      # bias gradient of q_proj (same pass for C <= 512)
         dz = conv_dgrad_raw(g1, wqf, dq, rows, 0, c, res=dout) if ctx.needs_input_grad[0] else None
         t = ctx.dtypes
         return (dz, dwq.to(t[0]), dbq.to(t[1]), dwo.to(t[2]), dbo.to(t[3]), sum_parts(dkp).to(t[4]),
