@@ -255,6 +255,23 @@ int unet_overlap_add(int32_t dtype, const void* pred, int32_t n_windows, int32_t
                      int32_t accumulate, int32_t finalize, int32_t mode, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Band-pair attention of CrossFrequencyCouplingAttentionV2 (csrc/attn.hip), bf16.
+ *
+ * unet_cfc_attn_fwd replaces the 25 F.scaled_dot_product_attention calls, their coupling-weighted fp32 sum and the
+ * band concatenation of models.py:431-462 with one launch:
+ *   out[n][l][i*c + h*hd + d] = sum_j coupling[i*n_bands + j] * softmax_keys(q_i k_j^T * scale) v_j     (hd = c / n_heads)
+ * q, k, v: [n_bands][n][l][c] (band-major stack of the grouped projections, channel = head*hd + d);
+ * coupling: n_bands^2 floats on the device (already softmaxed, models.py:428); out: [n][l][n_bands*c].
+ * o_pairs [n_bands][n_bands][n][l][c] and lse [n_bands][n_bands][n][n_heads][l] (fp32, log2 domain) are what
+ * backward needs; both null for inference.  hd must be a multiple of 8, at most 256.
+ *
+ * unet_cfc_attn_bwd: gradients of the same expression.  dout: [n][l][n_bands*c]; dq, dk, dv: [n_bands][n][l][c];
+ * dcoupling: n_bands^2 floats (gradient w.r.t. the softmaxed weights; overwritten); delta: scratch of lse's shape. */
+int unet_cfc_attn_fwd(int32_t dtype, const void* q, const void* k, const void* v, const float* coupling, int32_t n,
+                      int32_t l, int32_t c, int32_t n_heads, int32_t n_bands, float scale, void* out, void* o_pairs,
+                      float* lse, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Data path in front of the model (csrc/data.hip).
  *
  * unet_gather_windows: out[b][ch][:] = src[ch][starts[b] : starts[b]+w], optionally z-scored per (window, channel)

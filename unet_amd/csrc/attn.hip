@@ -1,0 +1,343 @@
+// Band-pair attention of CrossFrequencyCouplingAttentionV2 (models.py:395-462), bf16 MFMA:
+//   out[n, l, i*C + head*hd + d] = sum_j coupling[i][j] * softmax_keys(q_i k_j^T * scale) v_j
+// The reference issues 25 scaled_dot_product_attention calls per layer (every query band i against every key /
+// value band j), scales each result by the softmaxed coupling weight, sums in fp32 and concatenates the bands.
+// Here ONE launch does all of it: a workgroup owns 128 query rows of one (window, head, query band), walks the
+// five key/value bands with an online softmax each, and mixes the five results in registers; the output lands
+// directly in the [N, L, nb*C] layout out_proj consumes.  Nothing of size L x L ever exists.
+//
+// Orientation (32x32x16 MFMA): S^T = K Q^T puts a query row on the lane and the keys in the registers, so the
+// row max / row sum are in-lane reductions plus one exchange between the lane halves, the probabilities are the
+// B operand of O^T = V^T P^T straight from the accumulator registers (no LDS round trip), and the per-row
+// rescale of O^T is a per-lane scalar.  V^T comes from the row-major V tile by ds_read_b64_tr_b16.
+// K / V tiles of 64 keys are staged by buffer_load ... lds into xor-swizzled images (conflict-free for both the
+// 16-byte row reads and the transposed reads), double-buffered: one barrier per 64 keys.
+//
+// Backward = three kernels on the same tiles: rowdot (delta = c_ij <dO_i, O_ij>, d coupling), dQ (workgroup owns
+// query rows, walks keys) and dK/dV (workgroup owns keys, walks query rows; X = Q K^T keeps the key on the
+// lane so that dV^T = dO^T P and dK^T = Q^T dS again take the accumulator as the B operand).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+constexpr int AT_THREADS = 256;
+constexpr int AT_BQ = 128;   // rows owned by a workgroup (32 per wave)
+constexpr int AT_BK = 64;    // rows of a streamed tile
+constexpr unsigned AT_OOB = 0x80000000u;
+
+struct AttnK {
+  const __bf16 *q, *k, *v;   // [nb][N][L][C]
+  const float* coupling;     // [nb*nb] (already softmaxed)
+  __bf16* out;               // [N][L][nb*C]
+  __bf16* o_pairs;           // [nb][nb][N][L][C] or null
+  float* lse;                // [nb][nb][N][nh][L] or null; log2 domain: p = exp2(s*scale_log2 - lse)
+  // backward only
+  const __bf16* dout;        // [N][L][nb*C]
+  const float* delta;        // [nb][nb][N][nh][L]
+  __bf16 *dq, *dk, *dv;      // [nb][N][L][C]
+  int n, l, c, nh, nb, hd;
+  float scale, scale_log2;
+};
+
+template <int HDP> struct Cfg {
+  static constexpr int ROWB = HDP * 2;                 // bytes per tile row
+  static constexpr int CPR = HDP / 8;                  // 16-byte chunks per row
+  static constexpr int XM = CPR >= 16 ? 15 : CPR - 1;  // swizzle mask
+  static constexpr int KS = HDP / 16;                  // k-steps over the head dim
+  static constexpr int DT = HDP / 32;                  // 32-wide tiles over the head dim
+  static constexpr int TILE = AT_BK * ROWB;            // bytes of a [64][HDP] tile
+  static constexpr int PPW = TILE / 1024 / 4;          // 1 KiB pieces per wave
+};
+
+// chunk swizzle of the LDS images: rows that differ in their low two bits land in different 64-byte groups
+// (transposed reads), 16 rows of a ds_read_b128 lane group land on 16 different chunks
+__device__ __forceinline__ int xv(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__device__ __forceinline__ bf16x8 tr_pair(const char* lo, const char* hi) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lo);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)hi);
+  const s16x8 t = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, t);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s) {   // registers 8s..8s+7 -> bf16 fragment of k-step s
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (__bf16)x[8 * s + j];
+  return o;
+}
+
+// ---- streamed [64][HDP] tile: global -> LDS by buffer_load ... lds ---------------------------
+template <int HDP> struct TileLoader {
+  unsigned voff[Cfg<HDP>::PPW];
+  __device__ __forceinline__ void setup(int wave, int lane, int c, int hd) {
+#pragma unroll
+    for (int k = 0; k < Cfg<HDP>::PPW; ++k) {
+      const int lin = (wave * Cfg<HDP>::PPW + k) * 1024 + lane * 16;
+      const int row = lin / Cfg<HDP>::ROWB;
+      const int phys = (lin % Cfg<HDP>::ROWB) >> 4;
+      const int ch = phys ^ (xv(row) & Cfg<HDP>::XM);
+      voff[k] = ch * 8 < hd ? (unsigned)((row * c + ch * 8) * 2) : AT_OOB;
+    }
+  }
+  // rows row0 .. row0+63 of the slab behind rsrc (rows past its end arrive as zeros)
+  template <typename R> __device__ __forceinline__ void issue(R rsrc, char* tile, unsigned row0_bytes, int wave) const {
+#pragma unroll
+    for (int k = 0; k < Cfg<HDP>::PPW; ++k)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsrc, (__attribute__((address_space(3))) void*)(tile + (wave * Cfg<HDP>::PPW + k) * 1024), 16,
+          voff[k] + row0_bytes, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ auto slab_rsrc(const __bf16* base, long long elem_off, int l, int c, int hd) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(base + elem_off), 0, (unsigned)((((long long)l - 1) * c + hd) * 2),
+                                           0x00020000);
+}
+
+// per-lane LDS byte offsets of the two kinds of reads (see the header comment)
+template <int HDP> __device__ __forceinline__ int row_read_base(int lane) {   // + (s << 5) by xor, + 32*t*ROWB
+  const int r = lane & 31, h = lane >> 5;
+  return r * Cfg<HDP>::ROWB + ((h ^ (xv(r) & Cfg<HDP>::XM)) << 4);
+}
+template <int HDP> __device__ __forceinline__ int tr_read_base(int lane, int u) {   // ^ (dt << 6), + (32t + 16s)*ROWB
+  const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+  const int row = 8 * u + 4 * (g >> 1) + qq;
+  const int c_lo = 2 * (g & 1) + (pp >> 1);
+  return row * Cfg<HDP>::ROWB + ((c_lo ^ (xv(row) & Cfg<HDP>::XM)) << 4) + 8 * (pp & 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <int HDP>
+__global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK p) {
+  typedef Cfg<HDP> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K tile | V tile]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int nqt = (p.l + AT_BQ - 1) / AT_BQ;
+  const int qt = wg % nqt; wg /= nqt;
+  const int bi = wg % p.nb; wg /= p.nb;
+  const int head = wg % p.nh;
+  const int n = wg / p.nh;
+  const long long slab = (long long)p.l * p.c;
+  const int hoff = head * p.hd;
+  const int qrow = qt * AT_BQ + wave * 32 + r;
+  const bool row_ok = qrow < p.l;
+
+  bf16x8 qf[G::KS];
+  {
+    const __bf16* qp = p.q + ((long long)bi * p.n + n) * slab + (long long)qrow * p.c + hoff;
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) {
+      const int ch = 2 * s + h;
+      bf16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+      qf[s] = (row_ok && ch * 8 < p.hd) ? *reinterpret_cast<const bf16x8*>(qp + ch * 8) : z;
+    }
+  }
+
+  TileLoader<HDP> ld;
+  ld.setup(wave, lane, p.c, p.hd);
+  const int a0 = row_read_base<HDP>(lane);
+  const int vb0 = tr_read_base<HDP>(lane, 0), vb1 = tr_read_base<HDP>(lane, 1);
+
+  f32x16 acc[G::DT], mix[G::DT];
+#pragma unroll
+  for (int d = 0; d < G::DT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[d][e] = 0.f; mix[d][e] = 0.f; }
+  float m = -INFINITY, lsum = 0.f;
+
+  const int nkb = (p.l + AT_BK - 1) / AT_BK;
+  const int total = p.nb * nkb;
+  const unsigned tile_step = (unsigned)AT_BK * p.c * 2;
+
+  auto issue = [&](int j, int kb, int buf) {
+    const long long off = ((long long)j * p.n + n) * slab + hoff;
+    char* base = smem + buf * 2 * G::TILE;
+    ld.issue(slab_rsrc(p.k, off, p.l, p.c, p.hd), base, (unsigned)kb * tile_step, wave);
+    ld.issue(slab_rsrc(p.v, off, p.l, p.c, p.hd), base + G::TILE, (unsigned)kb * tile_step, wave);
+  };
+
+  issue(0, 0, 0);
+  int j = 0, kb = 0;
+  for (int it = 0; it < total; ++it) {
+    __syncthreads();   // tile `it` has landed (vmcnt(0) + barrier); every wave is done with the other buffer
+    {
+      int kb1 = kb + 1, j1 = j;
+      if (kb1 == nkb) { kb1 = 0; ++j1; }
+      if (it + 1 < total) issue(j1, kb1, (it + 1) & 1);
+    }
+    const char* kt = smem + (it & 1) * 2 * G::TILE;
+    const char* vt = kt + G::TILE;
+
+    // ---- S^T = K Q^T : [64 keys][32 query rows] as two 32x32 tiles --------------------------
+    f32x16 st[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[t][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(kt + ((a0 ^ (s << 5)) + t * 32 * G::ROWB));
+        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], st[t], 0, 0, 0);
+      }
+
+    // ---- online softmax over the keys (registers + the other lane half) ----------------------
+    const int key0 = kb * AT_BK;
+    if (key0 + AT_BK > p.l) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (key0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h >= p.l) st[t][e] = -INFINITY;
+    }
+    float mx = st[0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[t][e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;
+    const float m_new = fmaxf(m, mx);
+    if (__any(m_new > m)) {
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      lsum *= alpha;
+#pragma unroll
+      for (int d = 0; d < G::DT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[d][e] *= alpha;
+      m = m_new;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pe = __builtin_amdgcn_exp2f(fmaf(st[t][e], p.scale_log2, -m));
+        st[t][e] = pe;
+        lsum += pe;
+      }
+
+    // ---- O^T += V^T P^T ------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pb = pack8(st[t], s);
+        const int rowoff = (32 * t + 16 * s) * G::ROWB;
+#pragma unroll
+        for (int d = 0; d < G::DT; ++d) {
+          const bf16x8 a = tr_pair(vt + ((vb0 ^ (d << 6)) + rowoff), vt + ((vb1 ^ (d << 6)) + rowoff));
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, acc[d], 0, 0, 0);
+        }
+      }
+
+    // ---- end of a band pair: normalise, keep what backward needs, mix -----------------------------
+    if (kb + 1 == nkb) {
+      const float lt = lsum + __shfl_xor(lsum, 32, 64);
+      const float inv = 1.f / lt;
+      const float cw = p.coupling[bi * p.nb + j] * inv;
+      const long long pair = ((long long)bi * p.nb + j) * p.n + n;
+      if (p.lse && h == 0 && row_ok) p.lse[(pair * p.nh + head) * p.l + qrow] = m + __builtin_amdgcn_logf(lt);
+      __bf16* op = p.o_pairs ? p.o_pairs + pair * slab + (long long)qrow * p.c + hoff : nullptr;
+#pragma unroll
+      for (int d = 0; d < G::DT; ++d) {
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int dd = 32 * d + 8 * e4 + 4 * h;
+          if (op && row_ok && dd < p.hd) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[d][4 * e4 + e] * inv);
+            *reinterpret_cast<bf16x4*>(op + dd) = o;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            mix[d][4 * e4 + e] = fmaf(acc[d][4 * e4 + e], cw, mix[d][4 * e4 + e]);
+            acc[d][4 * e4 + e] = 0.f;
+          }
+        }
+      }
+      m = -INFINITY;
+      lsum = 0.f;
+      kb = 0;
+      ++j;
+    } else {
+      ++kb;
+    }
+  }
+
+  if (row_ok) {
+    __bf16* yp = p.out + ((long long)n * p.l + qrow) * ((long long)p.nb * p.c) + (long long)bi * p.c + hoff;
+#pragma unroll
+    for (int d = 0; d < G::DT; ++d)
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const int dd = 32 * d + 8 * e4 + 4 * h;
+        if (dd < p.hd) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (__bf16)mix[d][4 * e4 + e];
+          *reinterpret_cast<bf16x4*>(yp + dd) = o;
+        }
+      }
+  }
+}
+
+template <int HDP> int launch_fwd(const AttnK& p, hipStream_t st) {
+  const size_t lds = 4 * (size_t)Cfg<HDP>::TILE;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cfc_attn_fwd_kernel<HDP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    UNET_REQUIRE(e == hipSuccess, "cfc_attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+  }
+  const long long blocks = (long long)p.n * p.nh * p.nb * cdiv(p.l, AT_BQ);
+  hipLaunchKernelGGL(cfc_attn_fwd_kernel<HDP>, dim3((unsigned)blocks), dim3(AT_THREADS), lds, st, p);
+  UNET_LAUNCH_CHECK("cfc_attn_fwd");
+  return 0;
+}
+
+int check_geometry(const char* what, int n, int l, int c, int nh, int nb) {
+  UNET_REQUIRE(n > 0 && l > 0 && c > 0 && nh > 0 && nb > 0 && nb <= 8, "%s: bad shape n=%d l=%d c=%d heads=%d bands=%d",
+               what, n, l, c, nh, nb);
+  UNET_REQUIRE(c % nh == 0 && (c / nh) % 8 == 0 && c / nh <= 256,
+               "%s: head_dim %d must be a multiple of 8 and at most 256 (c=%d heads=%d)", what, c / nh, c, nh);
+  UNET_REQUIRE((long long)l * c * 2 < (1ll << 31), "%s: one [L, C] slab of %lld bytes exceeds a buffer descriptor", what,
+               (long long)l * c * 2);
+  UNET_REQUIRE((long long)n * nh * nb * cdiv(l, AT_BK) < (1ll << 31), "%s: grid too large", what);
+  return 0;
+}
+
+}  // namespace
+
+// no nulls except o_pairs / lse (both or neither: what backward needs)
+extern "C" int unet_cfc_attn_fwd(int32_t dtype, const void* q, const void* k, const void* v, const float* coupling,
+                                 int32_t n, int32_t l, int32_t c, int32_t n_heads, int32_t n_bands, float scale, void* out,
+                                 void* o_pairs, float* lse, void* stream) {
+  UNET_REQUIRE(dtype == UNET_BF16, "cfc_attn_fwd: bf16 only (dtype %d)", dtype);
+  UNET_REQUIRE(q && k && v && coupling && out, "cfc_attn_fwd: null pointer");
+  UNET_REQUIRE((o_pairs == nullptr) == (lse == nullptr), "cfc_attn_fwd: o_pairs and lse go together");
+  UNET_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out) && aligned16(o_pairs),
+               "cfc_attn_fwd: pointers must be 16-byte aligned");
+  if (check_geometry("cfc_attn_fwd", n, l, c, n_heads, n_bands)) return -1;
+  AttnK p = {};
+  p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.coupling = coupling;
+  p.out = (__bf16*)out; p.o_pairs = (__bf16*)o_pairs; p.lse = lse;
+  p.n = n; p.l = l; p.c = c; p.nh = n_heads; p.nb = n_bands; p.hd = c / n_heads;
+  p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (p.hd <= 32) return launch_fwd<32>(p, st);
+  if (p.hd <= 64) return launch_fwd<64>(p, st);
+  if (p.hd <= 128) return launch_fwd<128>(p, st);
+  return launch_fwd<256>(p, st);
+}

@@ -799,3 +799,23 @@ class ToNLCFn(torch.autograd.Function):
         check(lib.unet_nlc_to_ncl(_dt(dy), _dt(dx), _p(dy), _p(None), _p(None), _p(None), _p(None), _p(dx), n, c, t,
                                   _stream()), "unet_nlc_to_ncl")
         return dx, None
+
+
+# ---------------------------------------------------------------------------------------------
+# band-pair attention of CrossFrequencyCouplingAttentionV2 (csrc/attn.hip)
+# ---------------------------------------------------------------------------------------------
+def cfc_attn_forward_raw(q: Tensor, k: Tensor, v: Tensor, coupling: Tensor, n_heads: int, scale: float, keep: bool):
+    """q, k, v: [nb, N, L, C] bf16; coupling: [nb, nb] fp32 (softmaxed).  -> out [N, L, nb*C] (+ o_pairs, lse when
+    ``keep``: what backward needs)."""
+    for t in (q, k, v, coupling):
+        _need_cuda(t)
+    nb, n, l, c = q.shape
+    if q.dtype != torch.bfloat16 or not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
+        raise TypeError("cfc attention takes contiguous bfloat16 [nb, N, L, C] stacks")
+    coupling = coupling.float().contiguous()
+    out = torch.empty((n, l, nb * c), dtype=q.dtype, device=q.device)
+    o_pairs = torch.empty((nb, nb, n, l, c), dtype=q.dtype, device=q.device) if keep else None
+    lse = torch.empty((nb, nb, n, n_heads, l), dtype=torch.float32, device=q.device) if keep else None
+    check(_lib.load().unet_cfc_attn_fwd(_lib.BF16, _p(q), _p(k), _p(v), _p(coupling), n, l, c, n_heads, nb, float(scale), _p(out),
+                                  _p(o_pairs), _p(lse), _stream()), "unet_cfc_attn_fwd")
+    return out, o_pairs, lse
