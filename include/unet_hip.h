@@ -270,6 +270,13 @@ int unet_overlap_add(int32_t dtype, const void* pred, int32_t n_windows, int32_t
 int unet_cfc_attn_fwd(int32_t dtype, const void* q, const void* k, const void* v, const float* coupling, int32_t n,
                       int32_t l, int32_t c, int32_t n_heads, int32_t n_bands, float scale, void* out, void* o_pairs,
                       float* lse, void* stream);
+/* dcoupling_part: unet_cfc_attn_bwd_partials(n, l, n_bands) floats laid out [n_bands^2][partials]; the caller sums the
+ * last axis (no atomics: bit-reproducible).  Three launches: row dots <dO_i, O_ij>, dQ, dK/dV. */
+size_t unet_cfc_attn_bwd_partials(int32_t n, int32_t l, int32_t n_bands);
+int unet_cfc_attn_bwd(int32_t dtype, const void* q, const void* k, const void* v, const float* coupling,
+                      const void* o_pairs, const float* lse, const void* dout, int32_t n, int32_t l, int32_t c,
+                      int32_t n_heads, int32_t n_bands, float scale, void* dq, void* dk, void* dv, float* dcoupling_part,
+                      float* delta, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Data path in front of the model (csrc/data.hip).

@@ -45,6 +45,19 @@ def main():
         print(f"fwd N={n} L={l} C={c} heads={nh} bands={nb}: max abs err {err:.3e} (ref max {ref.abs().max().item():.2f})",
               flush=True)
         assert err < 3e-2, err
+        # backward against autograd through the fp32 expression
+        qr, kr, vr, cr = (t.detach().clone().requires_grad_(True) for t in (q, k, v, coupling))
+        g = torch.randn_like(ref).bfloat16()
+        reference(qr, kr, vr, cr, nh, scale).backward(g.float())
+        qh, kh, vh, ch = (t.detach().clone().requires_grad_(True) for t in (q, k, v, coupling))
+        ops.cfc_attention(qh, kh, vh, ch, nh, scale).backward(g)
+        torch.cuda.synchronize()
+        for name, a, b in (("dq", qh.grad, qr.grad), ("dk", kh.grad, kr.grad), ("dv", vh.grad, vr.grad),
+                           ("dcoupling", ch.grad, cr.grad)):
+            rel = ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
+            mx = (a.float() - b.float()).abs().max().item()
+            print(f"    {name}: rel l2 err {rel:.3e}, max abs {mx:.3e} (ref max {b.abs().max().item():.3f})", flush=True)
+            assert rel < 2e-2, (name, rel)
     # timing at the config-B bottleneck shape
     n, l, c, nh, nb = 16, 1024, 1024, 4, 5
     q, k, v = (torch.randn(nb, n, l, c, device=dev).bfloat16() for _ in range(3))
@@ -62,6 +75,18 @@ def main():
         ms = e0.elapsed_time(e1) / 5
         flops = nb * nb * n * nh * 4.0 * l * l * (c // nh)
         print(f"fwd keep={keep} N={n}: {ms:.2f} ms, {flops / ms / 1e9:.0f} TFLOP/s", flush=True)
+    qh, kh, vh, ch = (t.detach().clone().requires_grad_(True) for t in (q, k, v, coupling))
+    g = torch.randn(n, l, nb * c, device=dev).bfloat16()
+    for rep in range(3):
+        out = ops.cfc_attention(qh, kh, vh, ch, nh, 1 / 16.0)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out.backward(g)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    print(f"bwd N={n}: {ms:.2f} ms, {3.5 * flops / ms / 1e9:.0f} TFLOP/s (7 products)", flush=True)
 
 
 if __name__ == "__main__":

@@ -80,6 +80,9 @@ _SIGNATURES = {
     "unet_noise_augment": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _f32, _vp, _vp, _f32, _f32, _i32, _i32, _i32,
                                      _vp, _vp]),
     "unet_cfc_attn_fwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "unet_cfc_attn_bwd_partials": (C.c_size_t, [_i32, _i32, _i32]),
+    "unet_cfc_attn_bwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp,
+                                    _vp, _vp, _vp]),
     "unet_band_log_power": (C.c_int, [_vp, _vp, _i64, _i32, _i32, C.c_float, _vp, _vp]),
     "unet_overlap_add": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp, _i32, _i32, _i32, _vp]),
 }

@@ -84,7 +84,10 @@ template <int HDP> struct TileLoader {
     }
   }
   // rows row0 .. row0+63 of the slab behind rsrc (rows past its end arrive as zeros)
-  template <typename R> __device__ __forceinline__ void issue(R rsrc, char* tile, unsigned row0_bytes, int wave) const {
+  __device__ __forceinline__ void issue(const __bf16* base, long long elem_off, int l, int c, int hd, char* tile,
+                                        unsigned row0_bytes, int wave) const {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + elem_off), 0,
+                                                        (unsigned)((((long long)l - 1) * c + hd) * 2), 0x00020000);
 #pragma unroll
     for (int k = 0; k < Cfg<HDP>::PPW; ++k)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -92,11 +95,6 @@ template <int HDP> struct TileLoader {
           voff[k] + row0_bytes, 0, 0, 0);
   }
 };
-
-__device__ __forceinline__ auto slab_rsrc(const __bf16* base, long long elem_off, int l, int c, int hd) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)(base + elem_off), 0, (unsigned)((((long long)l - 1) * c + hd) * 2),
-                                           0x00020000);
-}
 
 // per-lane LDS byte offsets of the two kinds of reads (see the header comment)
 template <int HDP> __device__ __forceinline__ int row_read_base(int lane) {   // + (s << 5) by xor, + 32*t*ROWB
@@ -164,8 +162,8 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK
   auto issue = [&](int j, int kb, int buf) {
     const long long off = ((long long)j * p.n + n) * slab + hoff;
     char* base = smem + buf * 2 * G::TILE;
-    ld.issue(slab_rsrc(p.k, off, p.l, p.c, p.hd), base, (unsigned)kb * tile_step, wave);
-    ld.issue(slab_rsrc(p.v, off, p.l, p.c, p.hd), base + G::TILE, (unsigned)kb * tile_step, wave);
+    ld.issue(p.k, off, p.l, p.c, p.hd, base, (unsigned)kb * tile_step, wave);
+    ld.issue(p.v, off, p.l, p.c, p.hd, base + G::TILE, (unsigned)kb * tile_step, wave);
   };
 
   issue(0, 0, 0);
@@ -294,6 +292,353 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward 1/3: rowdot.  r = <dO_i[row, head], O_ij[row, head]>;  delta_ij = c_ij * r (the softmax-gradient row
+// term of pair (i, j), whose upstream gradient is c_ij dO_i);  d coupling[i][j] = sum r  (per-workgroup partials,
+// summed by the caller: no atomics, deterministic).  One wave per row, HBM-bound.
+// ---------------------------------------------------------------------------------------------
+constexpr int RD_ROWS = 64;   // rows per workgroup (16 per wave)
+
+__global__ __launch_bounds__(AT_THREADS) void cfc_attn_rowdot_kernel(const AttnK p, float* dc_part) {
+  __shared__ float part[4][264];    // per wave: one partial per 16-byte chunk (<= 8 heads x 32 chunks + pad)
+  __shared__ float wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pair = blockIdx.z, n = blockIdx.y;
+  const int bi = pair / p.nb;
+  const float cw = p.coupling[pair];
+  const int chunks = p.c >> 3, cph = p.hd >> 3;
+  const long long slab = (long long)p.l * p.c;
+  float tot = 0.f;
+  for (int rr = 0; rr < RD_ROWS / 4; ++rr) {
+    const int row = blockIdx.x * RD_ROWS + wave * (RD_ROWS / 4) + rr;
+    if (row >= p.l) break;                         // wave-uniform
+    const __bf16* dop = p.dout + ((long long)n * p.l + row) * ((long long)p.nb * p.c) + (long long)bi * p.c;
+    const __bf16* op = p.o_pairs + ((long long)pair * p.n + n) * slab + (long long)row * p.c;
+    for (int ch = lane; ch < chunks; ch += 64) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(dop + ch * 8);
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(op + ch * 8);
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc = fmaf((float)a[e], (float)b[e], acc);
+      part[wave][ch] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the wave's own LDS writes are visible to its lanes
+    if (lane < p.nh) {
+      float r = 0.f;
+      for (int k = 0; k < cph; ++k) r += part[wave][lane * cph + k];
+      const_cast<float*>(p.delta)[(((long long)pair * p.n + n) * p.nh + lane) * p.l + row] = cw * r;
+      tot += r;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  tot = wave_sum(tot);
+  if (lane == 0) wsum[wave] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    dc_part[((long long)pair * gridDim.y + n) * gridDim.x + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward 2/3: dQ_i = scale * sum_j sum_keys dS_ij K_j,  dS = P o (c_ij dO_i V_j^T - delta_ij).  Same walk as the
+// forward kernel; both tiles are read row-wise (S^T = K Q^T, dP^T = V dO^T) and K once more transposed.
+// ---------------------------------------------------------------------------------------------
+template <int HDP>
+__global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_dq_kernel(const AttnK p) {
+  typedef Cfg<HDP> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int nqt = (p.l + AT_BQ - 1) / AT_BQ;
+  const int qt = wg % nqt; wg /= nqt;
+  const int bi = wg % p.nb; wg /= p.nb;
+  const int head = wg % p.nh;
+  const int n = wg / p.nh;
+  const long long slab = (long long)p.l * p.c;
+  const int hoff = head * p.hd;
+  const int qrow = qt * AT_BQ + wave * 32 + r;
+  const bool row_ok = qrow < p.l;
+
+  bf16x8 qf[G::KS], dof[G::KS];
+  {
+    const __bf16* qp = p.q + ((long long)bi * p.n + n) * slab + (long long)qrow * p.c + hoff;
+    const __bf16* dp = p.dout + ((long long)n * p.l + qrow) * ((long long)p.nb * p.c) + (long long)bi * p.c + hoff;
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) {
+      const int ch = 2 * s + h;
+      bf16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+      const bool ok = row_ok && ch * 8 < p.hd;
+      qf[s] = ok ? *reinterpret_cast<const bf16x8*>(qp + ch * 8) : z;
+      dof[s] = ok ? *reinterpret_cast<const bf16x8*>(dp + ch * 8) : z;
+    }
+  }
+
+  TileLoader<HDP> ld;
+  ld.setup(wave, lane, p.c, p.hd);
+  const int a0 = row_read_base<HDP>(lane);
+  const int vb0 = tr_read_base<HDP>(lane, 0), vb1 = tr_read_base<HDP>(lane, 1);
+
+  f32x16 acc[G::DT];
+#pragma unroll
+  for (int d = 0; d < G::DT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+
+  const int nkb = (p.l + AT_BK - 1) / AT_BK;
+  const int total = p.nb * nkb;
+  const unsigned tile_step = (unsigned)AT_BK * p.c * 2;
+  auto issue = [&](int j, int kb, int buf) {
+    const long long off = ((long long)j * p.n + n) * slab + hoff;
+    char* base = smem + buf * 2 * G::TILE;
+    ld.issue(p.k, off, p.l, p.c, p.hd, base, (unsigned)kb * tile_step, wave);
+    ld.issue(p.v, off, p.l, p.c, p.hd, base + G::TILE, (unsigned)kb * tile_step, wave);
+  };
+
+  issue(0, 0, 0);
+  int j = 0, kb = 0;
+  float lse = 0.f, delta = 0.f, cw = 0.f;
+  for (int it = 0; it < total; ++it) {
+    if (kb == 0) {
+      const long long pair = ((long long)bi * p.nb + j) * p.n + n;
+      const long long si = (pair * p.nh + head) * p.l + qrow;
+      lse = row_ok ? p.lse[si] : INFINITY;        // rows past the end: p = 0
+      delta = row_ok ? p.delta[si] : 0.f;
+      cw = p.coupling[bi * p.nb + j];
+    }
+    __syncthreads();
+    {
+      int kb1 = kb + 1, j1 = j;
+      if (kb1 == nkb) { kb1 = 0; ++j1; }
+      if (it + 1 < total) issue(j1, kb1, (it + 1) & 1);
+    }
+    const char* kt = smem + (it & 1) * 2 * G::TILE;
+    const char* vt = kt + G::TILE;
+
+    f32x16 st[2], dp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { st[t][e] = 0.f; dp[t][e] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int o = (a0 ^ (s << 5)) + t * 32 * G::ROWB;
+        const bf16x8 ak = *reinterpret_cast<const bf16x8*>(kt + o);
+        const bf16x8 av = *reinterpret_cast<const bf16x8*>(vt + o);
+        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qf[s], st[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dof[s], dp[t], 0, 0, 0);
+      }
+    const int key0 = kb * AT_BK;
+    const bool ragged = key0 + AT_BK > p.l;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float pe = __builtin_amdgcn_exp2f(fmaf(st[t][e], p.scale_log2, -lse));
+        if (ragged && key0 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * h >= p.l) pe = 0.f;
+        st[t][e] = pe * fmaf(dp[t][e], cw, -delta);
+      }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 db = pack8(st[t], s);
+        const int rowoff = (32 * t + 16 * s) * G::ROWB;
+#pragma unroll
+        for (int d = 0; d < G::DT; ++d) {
+          const bf16x8 a = tr_pair(kt + ((vb0 ^ (d << 6)) + rowoff), kt + ((vb1 ^ (d << 6)) + rowoff));
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, db, acc[d], 0, 0, 0);
+        }
+      }
+    if (++kb == nkb) { kb = 0; ++j; }
+  }
+
+  if (row_ok) {
+    __bf16* yp = p.dq + ((long long)bi * p.n + n) * slab + (long long)qrow * p.c + hoff;
+#pragma unroll
+    for (int d = 0; d < G::DT; ++d)
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const int dd = 32 * d + 8 * e4 + 4 * h;
+        if (dd < p.hd) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (__bf16)(acc[d][4 * e4 + e] * p.scale);
+          *reinterpret_cast<bf16x4*>(yp + dd) = o;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward 3/3: dK_j, dV_j.  A workgroup owns 64 keys of one (window, head, key band) and walks the query rows
+// of all query bands, 64 at a time (Q and dO tiles).  Waves: 2 key groups of 32 x 2 halves of the streamed rows.
+// X = Q K^T has the key on the lane and the query rows in the registers, so P and dS are again B operands as
+// they come out of the accumulators: dV^T += dO^T (c_ij P), dK^T += Q^T dS (transposed reads of the dO / Q tiles).
+// The two row halves are summed through LDS at the end.
+// ---------------------------------------------------------------------------------------------
+template <int HDP>
+__global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_dkv_kernel(const AttnK p) {
+  typedef Cfg<HDP> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // K | V | Q | dO tiles, then 128 floats of row stats
+  char* const ktile = smem;
+  char* const vtile = smem + G::TILE;
+  char* const qtile = smem + 2 * G::TILE;
+  char* const dtile = smem + 3 * G::TILE;
+  float* const stats = reinterpret_cast<float*>(smem + 4 * G::TILE);   // [0..63] lse, [64..127] delta
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wave & 1, par = wave >> 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int nkt = (p.l + AT_BK - 1) / AT_BK;
+  const int ktl = wg % nkt; wg /= nkt;
+  const int bj = wg % p.nb; wg /= p.nb;
+  const int head = wg % p.nh;
+  const int n = wg / p.nh;
+  const long long slab = (long long)p.l * p.c;
+  const int hoff = head * p.hd;
+  const int ldo = p.nb * p.c;                          // row pitch of dout
+
+  TileLoader<HDP> ld, ldd;
+  ld.setup(wave, lane, p.c, p.hd);
+  ldd.setup(wave, lane, ldo, p.hd);
+  const int a0 = row_read_base<HDP>(lane);
+  const int vb0 = tr_read_base<HDP>(lane, 0), vb1 = tr_read_base<HDP>(lane, 1);
+
+  {
+    const long long off = ((long long)bj * p.n + n) * slab + hoff;
+    const unsigned row0 = (unsigned)ktl * AT_BK * p.c * 2;
+    ld.issue(p.k, off, p.l, p.c, p.hd, ktile, row0, wave);
+    ld.issue(p.v, off, p.l, p.c, p.hd, vtile, row0, wave);
+  }
+
+  f32x16 dka[G::DT], dva[G::DT];
+#pragma unroll
+  for (int d = 0; d < G::DT; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dka[d][e] = 0.f; dva[d][e] = 0.f; }
+
+  const int nqb = (p.l + AT_BK - 1) / AT_BK;
+  const int total = p.nb * nqb;
+  int i = 0, qb = 0;
+  for (int it = 0; it < total; ++it) {
+    const float cw = p.coupling[i * p.nb + bj];
+    __syncthreads();                     // every wave is done with the previous Q / dO tiles and stats
+    {
+      const unsigned row0 = (unsigned)qb * AT_BK;
+      ld.issue(p.q, ((long long)i * p.n + n) * slab + hoff, p.l, p.c, p.hd, qtile, row0 * p.c * 2, wave);
+      ldd.issue(p.dout, (long long)n * p.l * ldo + (long long)i * p.c + hoff, p.l, ldo, p.hd, dtile,
+                row0 * ldo * 2, wave);
+      if (tid < 128) {
+        const int rr = tid & 63;
+        const int row = qb * AT_BK + rr;
+        const long long si = ((((long long)i * p.nb + bj) * p.n + n) * p.nh + head) * p.l + row;
+        float v = tid < 64 ? INFINITY : 0.f;      // rows past the end: p = 0, delta = 0
+        if (row < p.l) v = tid < 64 ? p.lse[si] : p.delta[si];
+        stats[tid] = v;
+      }
+    }
+    __syncthreads();                     // tiles (vmcnt(0)) and stats (lgkmcnt(0)) are in LDS
+
+    // ---- X = Q K^T, dP = dO V^T : [32 query rows][32 keys] ----------------------------------------
+    f32x16 st, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) {
+      const int oq = (a0 ^ (s << 5)) + par * 32 * G::ROWB;
+      const int ok = (a0 ^ (s << 5)) + kg * 32 * G::ROWB;
+      const bf16x8 aq = *reinterpret_cast<const bf16x8*>(qtile + oq);
+      const bf16x8 bk = *reinterpret_cast<const bf16x8*>(ktile + ok);
+      const bf16x8 ad = *reinterpret_cast<const bf16x8*>(dtile + oq);
+      const bf16x8 bv = *reinterpret_cast<const bf16x8*>(vtile + ok);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bk, st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, bv, dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+      const int rl = 32 * par + 8 * e4 + 4 * h;           // local rows rl .. rl+3 live in registers 4*e4 .. 4*e4+3
+      const f32x4 ls = *reinterpret_cast<const f32x4*>(stats + rl);
+      const f32x4 de = *reinterpret_cast<const f32x4*>(stats + 64 + rl);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pe = __builtin_amdgcn_exp2f(fmaf(st[4 * e4 + e], p.scale_log2, -ls[e]));
+        st[4 * e4 + e] = pe * cw;                                   // c_ij P      -> dV
+        dp[4 * e4 + e] = pe * fmaf(dp[4 * e4 + e], cw, -de[e]);     // dS          -> dK
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 pb = pack8(st, s), db = pack8(dp, s);
+      const int rowoff = (32 * par + 16 * s) * G::ROWB;
+#pragma unroll
+      for (int d = 0; d < G::DT; ++d) {
+        const int o0 = (vb0 ^ (d << 6)) + rowoff, o1 = (vb1 ^ (d << 6)) + rowoff;
+        const bf16x8 adT = tr_pair(dtile + o0, dtile + o1);
+        dva[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(adT, pb, dva[d], 0, 0, 0);
+        const bf16x8 aqT = tr_pair(qtile + o0, qtile + o1);
+        dka[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aqT, db, dka[d], 0, 0, 0);
+      }
+    }
+    if (++qb == nqb) { qb = 0; ++i; }
+  }
+
+  // ---- sum the two row halves through LDS (all four tiles are free now), store --------------------
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);         // [kg][dk|dv][DT*16][64 lanes]
+  if (par == 1) {
+#pragma unroll
+    for (int d = 0; d < G::DT; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        red[((kg * 2 + 0) * G::DT * 16 + d * 16 + e) * 64 + lane] = dka[d][e];
+        red[((kg * 2 + 1) * G::DT * 16 + d * 16 + e) * 64 + lane] = dva[d][e];
+      }
+  }
+  __syncthreads();
+  if (par == 0) {
+    const int key = ktl * AT_BK + kg * 32 + r;
+    if (key < p.l) {
+      const long long o = ((long long)bj * p.n + n) * slab + (long long)key * p.c + hoff;
+#pragma unroll
+      for (int d = 0; d < G::DT; ++d)
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int dd = 32 * d + 8 * e4 + 4 * h;
+          if (dd < p.hd) {
+            bf16x4 ok, ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int x = d * 16 + 4 * e4 + e;
+              ok[e] = (__bf16)((dka[d][4 * e4 + e] + red[((kg * 2 + 0) * G::DT * 16 + x) * 64 + lane]) * p.scale);
+              ov[e] = (__bf16)(dva[d][4 * e4 + e] + red[((kg * 2 + 1) * G::DT * 16 + x) * 64 + lane]);
+            }
+            *reinterpret_cast<bf16x4*>(p.dk + o + dd) = ok;
+            *reinterpret_cast<bf16x4*>(p.dv + o + dd) = ov;
+          }
+        }
+    }
+  }
+}
+
+#define CFC_INSTANTIATE(HDP)                                             \
+  template __global__ void cfc_attn_fwd_kernel<HDP>(const AttnK);       \
+  template __global__ void cfc_attn_dq_kernel<HDP>(const AttnK);        \
+  template __global__ void cfc_attn_dkv_kernel<HDP>(const AttnK);
+CFC_INSTANTIATE(32)
+CFC_INSTANTIATE(64)
+CFC_INSTANTIATE(128)
+CFC_INSTANTIATE(256)
+#undef CFC_INSTANTIATE
+
 template <int HDP> int launch_fwd(const AttnK& p, hipStream_t st) {
   const size_t lds = 4 * (size_t)Cfg<HDP>::TILE;
   if (lds > 64 * 1024) {
@@ -304,6 +649,24 @@ template <int HDP> int launch_fwd(const AttnK& p, hipStream_t st) {
   const long long blocks = (long long)p.n * p.nh * p.nb * cdiv(p.l, AT_BQ);
   hipLaunchKernelGGL(cfc_attn_fwd_kernel<HDP>, dim3((unsigned)blocks), dim3(AT_THREADS), lds, st, p);
   UNET_LAUNCH_CHECK("cfc_attn_fwd");
+  return 0;
+}
+
+template <int HDP> int launch_bwd(const AttnK& p, hipStream_t st) {
+  const size_t lds_q = 4 * (size_t)Cfg<HDP>::TILE, lds_kv = 4 * (size_t)Cfg<HDP>::TILE + 512;
+  if (lds_kv > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cfc_attn_dq_kernel<HDP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cfc_attn_dkv_kernel<HDP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+    UNET_REQUIRE(e == hipSuccess, "cfc_attn_bwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+  }
+  const long long per = (long long)p.n * p.nh * p.nb;
+  hipLaunchKernelGGL(cfc_attn_dq_kernel<HDP>, dim3((unsigned)(per * cdiv(p.l, AT_BQ))), dim3(AT_THREADS), lds_q, st, p);
+  UNET_LAUNCH_CHECK("cfc_attn_bwd (dq)");
+  hipLaunchKernelGGL(cfc_attn_dkv_kernel<HDP>, dim3((unsigned)(per * cdiv(p.l, AT_BK))), dim3(AT_THREADS), lds_kv, st, p);
+  UNET_LAUNCH_CHECK("cfc_attn_bwd (dk, dv)");
   return 0;
 }
 
@@ -340,4 +703,40 @@ extern "C" int unet_cfc_attn_fwd(int32_t dtype, const void* q, const void* k, co
   if (p.hd <= 64) return launch_fwd<64>(p, st);
   if (p.hd <= 128) return launch_fwd<128>(p, st);
   return launch_fwd<256>(p, st);
+}
+
+extern "C" size_t unet_cfc_attn_bwd_partials(int32_t n, int32_t l, int32_t n_bands) {
+  return (size_t)n_bands * n_bands * n * cdiv(l, RD_ROWS);
+}
+
+// dcoupling_part: unet_cfc_attn_bwd_partials(n, l, n_bands) floats = [n_bands^2][n * row blocks]; the caller sums
+// the last axis.  delta: scratch of lse's shape.
+extern "C" int unet_cfc_attn_bwd(int32_t dtype, const void* q, const void* k, const void* v, const float* coupling,
+                                 const void* o_pairs, const float* lse, const void* dout, int32_t n, int32_t l, int32_t c,
+                                 int32_t n_heads, int32_t n_bands, float scale, void* dq, void* dk, void* dv,
+                                 float* dcoupling_part, float* delta, void* stream) {
+  UNET_REQUIRE(dtype == UNET_BF16, "cfc_attn_bwd: bf16 only (dtype %d)", dtype);
+  UNET_REQUIRE(q && k && v && coupling && o_pairs && lse && dout && dq && dk && dv && dcoupling_part && delta,
+               "cfc_attn_bwd: null pointer");
+  UNET_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o_pairs) && aligned16(dout) && aligned16(dq) &&
+                   aligned16(dk) && aligned16(dv),
+               "cfc_attn_bwd: pointers must be 16-byte aligned");
+  if (check_geometry("cfc_attn_bwd", n, l, c, n_heads, n_bands)) return -1;
+  UNET_REQUIRE((long long)l * n_bands * c * 2 < (1ll << 31), "cfc_attn_bwd: one [L, bands*C] slab exceeds a buffer descriptor");
+  UNET_REQUIRE(n <= 65535 && n_heads <= 64 && c / 8 <= 256, "cfc_attn_bwd: n=%d heads=%d c=%d out of range", n, n_heads, c);
+  AttnK p = {};
+  p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.coupling = coupling;
+  p.o_pairs = (__bf16*)const_cast<void*>(o_pairs); p.lse = const_cast<float*>(lse);
+  p.dout = (const __bf16*)dout; p.delta = delta;
+  p.dq = (__bf16*)dq; p.dk = (__bf16*)dk; p.dv = (__bf16*)dv;
+  p.n = n; p.l = l; p.c = c; p.nh = n_heads; p.nb = n_bands; p.hd = c / n_heads;
+  p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(cfc_attn_rowdot_kernel, dim3(cdiv(l, RD_ROWS), n, n_bands * n_bands), dim3(AT_THREADS), 0, st, p,
+                     dcoupling_part);
+  UNET_LAUNCH_CHECK("cfc_attn_bwd (rowdot)");
+  if (p.hd <= 32) return launch_bwd<32>(p, st);
+  if (p.hd <= 64) return launch_bwd<64>(p, st);
+  if (p.hd <= 128) return launch_bwd<128>(p, st);
+  return launch_bwd<256>(p, st);
 }

@@ -819,3 +819,36 @@ def cfc_attn_forward_raw(q: Tensor, k: Tensor, v: Tensor, coupling: Tensor, n_he
     check(_lib.load().unet_cfc_attn_fwd(_lib.BF16, _p(q), _p(k), _p(v), _p(coupling), n, l, c, n_heads, nb, float(scale), _p(out),
                                   _p(o_pairs), _p(lse), _stream()), "unet_cfc_attn_fwd")
     return out, o_pairs, lse
+
+
+class CfcAttnFn(torch.autograd.Function):
+    """out[n, l, i*C + h*hd + d] = sum_j coupling[i, j] * softmax(q_i k_j^T * scale) v_j  (models.py:431-462)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, coupling, n_heads, scale):
+        keep = any(ctx.needs_input_grad[:4])
+        coupling = coupling.float().contiguous()
+        out, o_pairs, lse = cfc_attn_forward_raw(q, k, v, coupling, n_heads, scale, keep)
+        if keep:
+            ctx.save_for_backward(q, k, v, coupling, o_pairs, lse)
+        ctx.n_heads, ctx.scale = n_heads, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, coupling, o_pairs, lse = ctx.saved_tensors
+        nb, n, l, c = q.shape
+        lib = _lib.load()
+        dout = dout.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        parts = torch.empty(lib.unet_cfc_attn_bwd_partials(n, l, nb), dtype=torch.float32, device=q.device).view(nb * nb, -1)
+        delta = torch.empty_like(lse)
+        check(lib.unet_cfc_attn_bwd(_lib.BF16, _p(q), _p(k), _p(v), _p(coupling), _p(o_pairs), _p(lse), _p(dout), n, l, c,
+                                    ctx.n_heads, nb, float(ctx.scale), _p(dq), _p(dk), _p(dv), _p(parts), _p(delta),
+                                    _stream()), "unet_cfc_attn_bwd")
+        return dq, dk, dv, parts.sum(dim=1).view(nb, nb), None, None
+
+
+def cfc_attention(q: Tensor, k: Tensor, v: Tensor, coupling: Tensor, n_heads: int, scale: float) -> Tensor:
+    """q, k, v: [nb, N, L, C] bf16 stacks of the per-band projections; coupling: [nb, nb] softmaxed weights."""
+    return CfcAttnFn.apply(q, k, v, coupling, n_heads, scale)
