@@ -1,0 +1,111 @@
+"""GPU: the band-pair attention kernels (csrc/attn.hip, through the C ABI) against
+  * an fp32 torch evaluation of the same expression on the same bf16 inputs (forward, dq, dk, dv, d coupling) over
+    head sizes 8..256, ragged lengths and band counts;
+  * outputs frozen from the reference's CrossFrequencyCouplingAttentionV2 (tests/golden/attn_cross_freq_v2.npz):
+    the whole module in fp32 (torch products, <= 1e-4 / 1e-3) and in bf16 (HIP kernels, bars below).
+bf16 bars: the kernel rounds P and dS to bf16 before the second product, as every flash kernel does: forward
+<= 3e-2 absolute on O(1) outputs, gradients <= 2e-2 relative L2 against the fp32 expression."""
+import math
+
+import pytest
+import torch
+
+from tests.test_oracle_attn import CASES, above_floor, load_case, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def expression(q, k, v, coupling, nh, scale):
+    nb, n, l, c = q.shape
+    hd = c // nh
+    sp = lambda t: t.float().view(nb, n, l, nh, hd).permute(0, 1, 3, 2, 4)      # [nb, N, nh, L, hd]
+    qf, kf, vf = sp(q), sp(k), sp(v)
+    outs = []
+    for i in range(nb):
+        acc = 0
+        for j in range(nb):
+            p = torch.softmax(qf[i] @ kf[j].transpose(-1, -2) * scale, dim=-1)
+            acc = acc + coupling[i, j] * (p @ vf[j])
+        outs.append(acc.permute(0, 2, 1, 3).reshape(n, l, c))
+    return torch.cat(outs, dim=2)
+
+
+SHAPES = [(2, 64, 32, 4, 5), (1, 200, 64, 2, 3), (2, 130, 256, 4, 5), (1, 257, 512, 4, 2), (1, 300, 1024, 4, 5),
+          (2, 100, 96, 4, 5), (3, 1, 64, 2, 2), (1, 65, 48, 2, 1)]
+
+
+@pytest.mark.parametrize("n,l,c,nh,nb", SHAPES)
+def test_kernels_match_fp32_expression(n, l, c, nh, nb):
+    from unet_amd import ops
+    torch.manual_seed(l * 7 + c)
+    q, k, v = (torch.randn(nb, n, l, c, device="cuda").mul_(1.5).bfloat16() for _ in range(3))
+    coupling = torch.softmax(torch.randn(nb, nb, device="cuda"), dim=-1)
+    scale = 1.0 / math.sqrt(c // nh)
+    qr, kr, vr, cr = (t.detach().clone().requires_grad_(True) for t in (q, k, v, coupling))
+    ref = expression(qr, kr, vr, cr, nh, scale)
+    g = torch.randn_like(ref).bfloat16()
+    ref.backward(g.float())
+    qh, kh, vh, ch = (t.detach().clone().requires_grad_(True) for t in (q, k, v, coupling))
+    out = ops.cfc_attention(qh, kh, vh, ch, nh, scale)
+    assert (out.float() - ref).abs().max().item() < 3e-2
+    out.backward(g)
+    for name, a, b in (("dq", qh.grad, qr.grad), ("dk", kh.grad, kr.grad), ("dv", vh.grad, vr.grad),
+                       ("dcoupling", ch.grad, cr.grad)):
+        a, b = a.double().cpu(), b.double().cpu()      # (+1e-4: with one key, dq and dk are exactly zero)
+        assert (a - b).norm().item() <= 2e-2 * b.norm().item() + 1e-4, name
+    # inference (nothing kept for backward) writes the same output bits
+    with torch.no_grad():
+        out2 = ops.cfc_attention(q, k, v, coupling, nh, scale)
+    assert torch.equal(out2, out.detach())
+
+
+def test_rejects_what_the_kernel_cannot_do():
+    from unet_amd import ops
+    q = torch.randn(2, 1, 16, 24, device="cuda").bfloat16()         # head_dim 12: not a multiple of 8
+    cp = torch.full((2, 2), 0.5, device="cuda")
+    with pytest.raises(RuntimeError, match="head_dim"):
+        ops.cfc_attention(q, q, q, cp, 2, 1.0)
+    with pytest.raises(TypeError):
+        ops.cfc_attention(q.float(), q.float(), q.float(), cp, 1, 1.0)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.cfc_attention(q.cpu(), q.cpu(), q.cpu(), cp.cpu(), 1, 1.0)
+
+
+def _module(g, dtype):
+    from unet_amd.model import CrossFrequencyCouplingAttentionV2
+    m = CrossFrequencyCouplingAttentionV2(g["c"], n_heads=g["nh"]).cuda()
+    m.load_state_dict(g["sd"], strict=True)
+    return m
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_module_fp32_matches_reference(name):
+    g = load_case(name)
+    m = _module(g, torch.float32)
+    x = g["x"].cuda().requires_grad_(True)
+    y = m(x)
+    assert rel(y.detach().cpu(), g["y"]) < 1e-4
+    (y * g["gy"].cuda()).sum().backward()
+    assert rel(x.grad.cpu(), g["dx"]) < 1e-3
+    grads = dict(m.named_parameters())
+    for k, ref in above_floor(g["grads"]).items():
+        assert rel(grads[k].grad.cpu(), ref) < 1e-3, k
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_module_bf16_kernels_close_to_reference(name):
+    """bf16 activations end to end (band signals, q/k/v, attention on the HIP kernels, out_proj): output <= 2e-2,
+    input / parameter gradients <= 6e-2 relative L2 against the reference's fp32 run (coupling_weights and gate are
+    a handful of numbers that are sums over everything: 3x)."""
+    g = load_case(name)
+    m = _module(g, torch.bfloat16)
+    x = g["x"].cuda().bfloat16().requires_grad_(True)
+    y = m(x)
+    assert y.dtype == torch.bfloat16
+    assert rel(y.detach().float().cpu(), g["y"]) < 2e-2
+    (y.float() * g["gy"].cuda()).sum().backward()
+    assert rel(x.grad.float().cpu(), g["dx"]) < 6e-2
+    grads = dict(m.named_parameters())
+    for k, ref in above_floor(g["grads"]).items():
+        bar = 1.8e-1 if ref.numel() <= 25 else 6e-2
+        assert rel(grads[k].grad.cpu(), ref) < bar, (k, rel(grads[k].grad.cpu(), ref))

@@ -161,9 +161,10 @@ class CrossFrequencyCouplingAttentionV2(nn.Module):
 
     Channels-last throughout: the band split is an rFFT along the row axis of the ``[N, L, C]`` tensor (rocFFT,
     no transposes), the per-band projections and out_proj run on the HIP conv kernels (the grouped Conv1d is five
-    independent C x C convs on strided views of one buffer), the 25 attention products go through
-    ``scaled_dot_product_attention``.  A hand-written MFMA flash kernel for these products (head_dim = C/4 = 256 at
-    config B, 107 GFLOP per window) is the open item of this row; everything around them is on the HIP path.
+    independent C x C convs on strided views of one buffer), and in bf16 the 25 attention products, their
+    coupling-weighted sum and the concatenation are ONE launch of the band-pair flash kernel (``csrc/attn.hip``,
+    head_dim = C/4 = 256 at config B, 107 GFLOP per window; backward = 3 launches).  fp32 parity runs evaluate the
+    same products with ``scaled_dot_product_attention``.
     """
 
     def __init__(self, channels: int, n_heads: int = 4, sample_rate: float = 1000.0, bands=None, chunk_size: int = 256,
@@ -217,12 +218,18 @@ class CrossFrequencyCouplingAttentionV2(nn.Module):
         def project(conv):
             w = conv.weight.view(nb, c, c, 1)
             b = conv.bias.view(nb, c)
-            # band i: its own C x C conv on the strided view bands[:, i]; -> [N, heads, L, hd]
-            return [ops.conv(bands[:, i], w[i].permute(2, 0, 1), b[i], g1, t).view(n, t, nh, hd).transpose(1, 2)
-                    for i in range(nb)]
+            # band i: its own C x C conv on the strided view bands[:, i]; -> [N, L, C], channel = head * hd + d
+            return [ops.conv(bands[:, i], w[i].permute(2, 0, 1), b[i], g1, t) for i in range(nb)]
 
         q, k, v = project(self.proj_q), project(self.proj_k), project(self.proj_v)
         coupling = F.softmax(self.coupling_weights.float(), dim=-1)
+        if x.dtype == torch.bfloat16 and hd % 8 == 0 and hd <= 256:
+            # all nb x nb products, their coupling-weighted sum and the band concatenation in one HIP launch
+            cat = ops.cfc_attention(torch.stack(q), torch.stack(k), torch.stack(v), coupling, nh, self.scale)
+            out = ops.conv(cat, self.out_proj.weight.permute(2, 0, 1), self.out_proj.bias, g1, t)
+            return (x.float() + self.gate.float() * out.float()).to(x.dtype)
+        # fp32 (parity runs): the same products through torch
+        q, k, v = ([a.view(n, t, nh, hd).transpose(1, 2) for a in z] for z in (q, k, v))
         outs = []
         for i in range(nb):
             acc = None
