@@ -159,8 +159,8 @@ class CrossFrequencyCouplingAttentionV2(nn.Module):
     grouped 1x1 q/k/v projections per band, every query band attends to every key/value band, outputs mixed by
     softmax(coupling_weights), 1x1 out_proj, gated residual.  Same parameters / state-dict keys as the reference.
 
-    Channels-last throughout: the band split is an rFFT along the row axis of the ``[N, L, C]`` tensor (rocFFT,
-    no transposes), the per-band projections and out_proj run on the HIP conv kernels (the grouped Conv1d is five
+    Channels-last throughout: the band split runs along the row axis of the ``[N, L, C]`` tensor (fp32: rocFFT;
+    bf16: the same linear operator as one library GEMM, see ``_band_operator``; no transposes), the per-band projections and out_proj run on the HIP conv kernels (the grouped Conv1d is five
     independent C x C convs on strided views of one buffer), and in bf16 the 25 attention products, their
     coupling-weighted sum and the concatenation are ONE launch of the band-pair flash kernel (``csrc/attn.hip``,
     head_dim = C/4 = 256 at config B, 107 GFLOP per window; backward = 3 launches).  fp32 parity runs evaluate the
@@ -206,13 +206,43 @@ class CrossFrequencyCouplingAttentionV2(nn.Module):
             self._filters_on[key] = self._filters_cache.to(device)
         return self._filters_on[key]
 
-    def forward_nlc(self, x: Tensor) -> Tensor:
+    GEMM_SPLIT_MAX_LEN = 4096
+
+    def _band_operator(self, T: int, device) -> Tensor:
+        """The band split irfft(rfft(x) * filt_b) is linear in x: row (b, l) of this [nb*T, 2T] bf16 matrix is the
+        response of band b at position l to an impulse at each position, as a bf16 high part followed by the bf16
+        remainder (K = 2T against [x; x]: bf16 inputs are exact, products accumulate in fp32, so the operator is
+        applied to ~2^-17 and the only rounding left is the bf16 store the FFT path has as well)."""
+        key = (T, str(torch.device(device)))
+        cache = self.__dict__.setdefault("_band_ops", {})
+        if key not in cache:
+            filt = self._build_bandpass_filters_batched(T, device).float()                        # [nb, F]
+            eye_f = torch.fft.rfft(torch.eye(T, device=device, dtype=torch.float32), dim=0)       # [F, T]
+            h = torch.fft.irfft(filt[:, :, None] * eye_f[None], n=T, dim=1)                       # [nb, T(l), T(l')]
+            h = h.reshape(self.n_bands * T, T)
+            hi = h.bfloat16()
+            lo = (h - hi.float()).bfloat16()
+            cache.clear()
+            cache[key] = torch.cat([hi, lo], dim=1).contiguous()
+        return cache[key]
+
+    def _split_bands(self, x: Tensor) -> Tensor:
+        """[N, L, C] -> [N, nb, L, C] band signals (models.py:314-340)."""
         n, t, c = x.shape
-        nb, nh, hd = self.n_bands, self.n_heads, self.head_dim
+        if x.dtype == torch.bfloat16 and t <= self.GEMM_SPLIT_MAX_LEN:
+            # one plain library GEMM per window batch ([nb*L, 2L] @ [2L, C]) instead of rFFT, a complex product
+            # over [N, nb, F, C], nb inverse FFTs and the casts around them; backward is the transposed GEMM
+            op = self._band_operator(t, x.device)
+            return torch.matmul(op, torch.cat([x, x], dim=1)).view(n, self.n_bands, t, c)
         filt = self._build_bandpass_filters_batched(t, x.device)                       # [nb, F]
         xf = torch.fft.rfft(x.float(), dim=1)                                          # [N, F, C]
         bands = torch.fft.irfft(xf.unsqueeze(1) * filt[None, :, :, None], n=t, dim=2)  # [N, nb, L, C]
-        bands = bands.to(x.dtype)
+        return bands.to(x.dtype)
+
+    def forward_nlc(self, x: Tensor) -> Tensor:
+        n, t, c = x.shape
+        nb, nh, hd = self.n_bands, self.n_heads, self.head_dim
+        bands = self._split_bands(x)
         g1 = ops.geom_conv(1)
 
         def project(conv):
