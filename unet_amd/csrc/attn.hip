@@ -478,20 +478,17 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_dq_kernel(const AttnK 
 
 // ---------------------------------------------------------------------------------------------
 // backward 3/3: dK_j, dV_j.  A workgroup owns 64 keys of one (window, head, key band) and walks the query rows
-// of all query bands, 64 at a time (Q and dO tiles).  Waves: 2 key groups of 32 x 2 halves of the streamed rows.
-// X = Q K^T has the key on the lane and the query rows in the registers, so P and dS are again B operands as
-// they come out of the accumulators: dV^T += dO^T (c_ij P), dK^T += Q^T dS (transposed reads of the dO / Q tiles).
+// of all query bands, 64 at a time (Q and dO tiles, double-buffered).  Waves: 2 key groups of 32 x 2 halves of
+// the streamed rows.  The wave's own K and V rows stay in registers as B operands: X = Q K^T has the key on the
+// lane and the query rows in the registers, so P and dS are again B operands as they come out of the
+// accumulators: dV^T += dO^T (c_ij P), dK^T += Q^T dS (transposed reads of the dO / Q tiles).
 // The two row halves are summed through LDS at the end.
 // ---------------------------------------------------------------------------------------------
 template <int HDP>
 __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_dkv_kernel(const AttnK p) {
   typedef Cfg<HDP> G;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // K | V | Q | dO tiles, then 128 floats of row stats
-  char* const ktile = smem;
-  char* const vtile = smem + G::TILE;
-  char* const qtile = smem + 2 * G::TILE;
-  char* const dtile = smem + 3 * G::TILE;
-  float* const stats = reinterpret_cast<float*>(smem + 4 * G::TILE);   // [0..63] lse, [64..127] delta
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][Q tile | dO tile], then [2][128] row stats
+  float* const stats = reinterpret_cast<float*>(smem + 4 * G::TILE);   // per buffer: [0..63] lse, [64..127] delta
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kg = wave & 1, par = wave >> 1;
@@ -506,19 +503,26 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_dkv_kernel(const AttnK
   const long long slab = (long long)p.l * p.c;
   const int hoff = head * p.hd;
   const int ldo = p.nb * p.c;                          // row pitch of dout
+  const int key = ktl * AT_BK + kg * 32 + r;
+  const long long kvo = ((long long)bj * p.n + n) * slab + (long long)key * p.c + hoff;
+
+  bf16x8 kf[G::KS], vf[G::KS];
+#pragma unroll
+  for (int s = 0; s < G::KS; ++s) {
+    const int ch = 2 * s + h;
+    bf16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+    const bool ok = key < p.l && ch * 8 < p.hd;
+    kf[s] = ok ? *reinterpret_cast<const bf16x8*>(p.k + kvo + ch * 8) : z;
+    vf[s] = ok ? *reinterpret_cast<const bf16x8*>(p.v + kvo + ch * 8) : z;
+  }
 
   TileLoader<HDP> ld, ldd;
   ld.setup(wave, lane, p.c, p.hd);
   ldd.setup(wave, lane, ldo, p.hd);
-  const int a0 = row_read_base<HDP>(lane);
-  const int vb0 = tr_read_base<HDP>(lane, 0), vb1 = tr_read_base<HDP>(lane, 1);
-
-  {
-    const long long off = ((long long)bj * p.n + n) * slab + hoff;
-    const unsigned row0 = (unsigned)ktl * AT_BK * p.c * 2;
-    ld.issue(p.k, off, p.l, p.c, p.hd, ktile, row0, wave);
-    ld.issue(p.v, off, p.l, p.c, p.hd, vtile, row0, wave);
-  }
+  const int a0 = row_read_base<HDP>(lane) + par * 32 * G::ROWB;
+  const int vb0 = tr_read_base<HDP>(lane, 0) + par * 32 * G::ROWB, vb1 = tr_read_base<HDP>(lane, 1) + par * 32 * G::ROWB;
 
   f32x16 dka[G::DT], dva[G::DT];
 #pragma unroll
@@ -528,25 +532,40 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_dkv_kernel(const AttnK
 
   const int nqb = (p.l + AT_BK - 1) / AT_BK;
   const int total = p.nb * nqb;
+
+  auto issue = [&](int i, int qb, int buf) {
+    const unsigned row0 = (unsigned)qb * AT_BK;
+    char* base = smem + buf * 2 * G::TILE;
+    ld.issue(p.q, ((long long)i * p.n + n) * slab + hoff, p.l, p.c, p.hd, base, row0 * p.c * 2, wave);
+    ldd.issue(p.dout, (long long)n * p.l * ldo + (long long)i * p.c + hoff, p.l, ldo, p.hd, base + G::TILE, row0 * ldo * 2,
+              wave);
+  };
+  auto load_stat = [&](int i, int qb) {            // threads 0..63: lse, 64..127: delta of the tile's rows
+    float v = tid < 64 ? INFINITY : 0.f;           // rows past the end: p = 0, delta = 0
+    const int row = qb * AT_BK + (tid & 63);
+    if (tid < 128 && row < p.l) {
+      const long long si = ((((long long)i * p.nb + bj) * p.n + n) * p.nh + head) * p.l + row;
+      v = tid < 64 ? p.lse[si] : p.delta[si];
+    }
+    return v;
+  };
+
+  issue(0, 0, 0);
+  if (tid < 128) stats[tid] = load_stat(0, 0);
   int i = 0, qb = 0;
   for (int it = 0; it < total; ++it) {
     const float cw = p.coupling[i * p.nb + bj];
-    __syncthreads();                     // every wave is done with the previous Q / dO tiles and stats
-    {
-      const unsigned row0 = (unsigned)qb * AT_BK;
-      ld.issue(p.q, ((long long)i * p.n + n) * slab + hoff, p.l, p.c, p.hd, qtile, row0 * p.c * 2, wave);
-      ldd.issue(p.dout, (long long)n * p.l * ldo + (long long)i * p.c + hoff, p.l, ldo, p.hd, dtile,
-                row0 * ldo * 2, wave);
-      if (tid < 128) {
-        const int rr = tid & 63;
-        const int row = qb * AT_BK + rr;
-        const long long si = ((((long long)i * p.nb + bj) * p.n + n) * p.nh + head) * p.l + row;
-        float v = tid < 64 ? INFINITY : 0.f;      // rows past the end: p = 0, delta = 0
-        if (row < p.l) v = tid < 64 ? p.lse[si] : p.delta[si];
-        stats[tid] = v;
-      }
+    int qb1 = qb + 1, i1 = i;
+    if (qb1 == nqb) { qb1 = 0; ++i1; }
+    __syncthreads();   // tile `it` and its stats are in LDS; every wave is done with the other buffer
+    float stat_next = 0.f;
+    if (it + 1 < total) {
+      issue(i1, qb1, (it + 1) & 1);
+      stat_next = load_stat(i1, qb1);
     }
-    __syncthreads();                     // tiles (vmcnt(0)) and stats (lgkmcnt(0)) are in LDS
+    const char* qtile = smem + (it & 1) * 2 * G::TILE;
+    const char* dtile = qtile + G::TILE;
+    const float* st_in = stats + (it & 1) * 128;
 
     // ---- X = Q K^T, dP = dO V^T : [32 query rows][32 keys] ----------------------------------------
     f32x16 st, dp;
@@ -554,20 +573,17 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_dkv_kernel(const AttnK
     for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
     for (int s = 0; s < G::KS; ++s) {
-      const int oq = (a0 ^ (s << 5)) + par * 32 * G::ROWB;
-      const int ok = (a0 ^ (s << 5)) + kg * 32 * G::ROWB;
-      const bf16x8 aq = *reinterpret_cast<const bf16x8*>(qtile + oq);
-      const bf16x8 bk = *reinterpret_cast<const bf16x8*>(ktile + ok);
-      const bf16x8 ad = *reinterpret_cast<const bf16x8*>(dtile + oq);
-      const bf16x8 bv = *reinterpret_cast<const bf16x8*>(vtile + ok);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, bk, st, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, bv, dp, 0, 0, 0);
+      const int o = a0 ^ (s << 5);
+      const bf16x8 aq = *reinterpret_cast<const bf16x8*>(qtile + o);
+      const bf16x8 ad = *reinterpret_cast<const bf16x8*>(dtile + o);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[s], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[s], dp, 0, 0, 0);
     }
 #pragma unroll
     for (int e4 = 0; e4 < 4; ++e4) {
       const int rl = 32 * par + 8 * e4 + 4 * h;           // local rows rl .. rl+3 live in registers 4*e4 .. 4*e4+3
-      const f32x4 ls = *reinterpret_cast<const f32x4*>(stats + rl);
-      const f32x4 de = *reinterpret_cast<const f32x4*>(stats + 64 + rl);
+      const f32x4 ls = *reinterpret_cast<const f32x4*>(st_in + rl);
+      const f32x4 de = *reinterpret_cast<const f32x4*>(st_in + 64 + rl);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float pe = __builtin_amdgcn_exp2f(fmaf(st[4 * e4 + e], p.scale_log2, -ls[e]));
@@ -578,7 +594,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_dkv_kernel(const AttnK
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const bf16x8 pb = pack8(st, s), db = pack8(dp, s);
-      const int rowoff = (32 * par + 16 * s) * G::ROWB;
+      const int rowoff = 16 * s * G::ROWB;
 #pragma unroll
       for (int d = 0; d < G::DT; ++d) {
         const int o0 = (vb0 ^ (d << 6)) + rowoff, o1 = (vb1 ^ (d << 6)) + rowoff;
@@ -588,10 +604,12 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_dkv_kernel(const AttnK
         dka[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aqT, db, dka[d], 0, 0, 0);
       }
     }
-    if (++qb == nqb) { qb = 0; ++i; }
+    if (it + 1 < total && tid < 128) stats[((it + 1) & 1) * 128 + tid] = stat_next;
+    qb = qb1;
+    i = i1;
   }
 
-  // ---- sum the two row halves through LDS (all four tiles are free now), store --------------------
+  // ---- sum the two row halves through LDS (both buffers are free now), store ------------------------
   __syncthreads();
   float* red = reinterpret_cast<float*>(smem);         // [kg][dk|dv][DT*16][64 lanes]
   if (par == 1) {
@@ -604,28 +622,24 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_dkv_kernel(const AttnK
       }
   }
   __syncthreads();
-  if (par == 0) {
-    const int key = ktl * AT_BK + kg * 32 + r;
-    if (key < p.l) {
-      const long long o = ((long long)bj * p.n + n) * slab + (long long)key * p.c + hoff;
+  if (par == 0 && key < p.l) {
 #pragma unroll
-      for (int d = 0; d < G::DT; ++d)
+    for (int d = 0; d < G::DT; ++d)
 #pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-          const int dd = 32 * d + 8 * e4 + 4 * h;
-          if (dd < p.hd) {
-            bf16x4 ok, ov;
+      for (int e4 = 0; e4 < 4; ++e4) {
+        const int dd = 32 * d + 8 * e4 + 4 * h;
+        if (dd < p.hd) {
+          bf16x4 ok, ov;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int x = d * 16 + 4 * e4 + e;
-              ok[e] = (__bf16)((dka[d][4 * e4 + e] + red[((kg * 2 + 0) * G::DT * 16 + x) * 64 + lane]) * p.scale);
-              ov[e] = (__bf16)(dva[d][4 * e4 + e] + red[((kg * 2 + 1) * G::DT * 16 + x) * 64 + lane]);
-            }
-            *reinterpret_cast<bf16x4*>(p.dk + o + dd) = ok;
-            *reinterpret_cast<bf16x4*>(p.dv + o + dd) = ov;
+          for (int e = 0; e < 4; ++e) {
+            const int x = d * 16 + 4 * e4 + e;
+            ok[e] = (__bf16)((dka[d][4 * e4 + e] + red[((kg * 2 + 0) * G::DT * 16 + x) * 64 + lane]) * p.scale);
+            ov[e] = (__bf16)(dva[d][4 * e4 + e] + red[((kg * 2 + 1) * G::DT * 16 + x) * 64 + lane]);
           }
+          *reinterpret_cast<bf16x4*>(p.dk + kvo + dd) = ok;
+          *reinterpret_cast<bf16x4*>(p.dv + kvo + dd) = ov;
         }
-    }
+      }
   }
 }
 
@@ -653,7 +667,7 @@ template <int HDP> int launch_fwd(const AttnK& p, hipStream_t st) {
 }
 
 template <int HDP> int launch_bwd(const AttnK& p, hipStream_t st) {
-  const size_t lds_q = 4 * (size_t)Cfg<HDP>::TILE, lds_kv = 4 * (size_t)Cfg<HDP>::TILE + 512;
+  const size_t lds_q = 4 * (size_t)Cfg<HDP>::TILE, lds_kv = 4 * (size_t)Cfg<HDP>::TILE + 1024;
   if (lds_kv > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cfc_attn_dq_kernel<HDP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
