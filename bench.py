@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--conditioning", default="odor_onehot", choices=["odor_onehot", "spectro_temporal"],
                     help="spectro_temporal: the SpectroTemporalEncoder (train.py --conditioning default) runs inside the "
                          "step and trains with the model; the headline config is odor_onehot")
+    ap.add_argument("--attention", default="none", choices=["none", "cross_freq_v2"],
+                    help="cross_freq_v2: the phase-four / phase-five bottleneck attention (band-pair flash kernels); the "
+                         "headline config B has none")
     ap.add_argument("--graph", action="store_true", help="replay the captured HIP graph also for N > 1 (all-reduce runs "
                     "between the two graphs, not overlapped); default for N > 1 is the eager hook-driven path")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one (hook-driven overlapped "
@@ -70,11 +73,12 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(n_windows: int):
+def cpu_baseline(n_windows: int, cfg=None):
     """Oracle (CPU port of the reference path) on a bounded sample of the same workload."""
     from oracle import condunet_oracle as O
     threads = torch.get_num_threads()
-    sd = O.init_state_dict(CONFIG_B, seed=0)
+    cfg = cfg or CONFIG_B
+    sd = O.init_state_dict(cfg, seed=0)
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
     run_sd = dict(sd)
     run_sd.update(leaves)
@@ -85,7 +89,7 @@ def cpu_baseline(n_windows: int):
     reps = 2
     t0 = time.perf_counter()
     for _ in range(reps):
-        loss = O.train_step_loss(run_sd, CONFIG_B, ob, tgt, odor_ids=ids)
+        loss = O.train_step_loss(run_sd, cfg, ob, tgt, odor_ids=ids)
         loss.backward()
     dt = time.perf_counter() - t0
     return {"value": reps * n_windows / dt, "unit": "windows/s", "cores": threads, "kind": "port",
@@ -114,7 +118,8 @@ def main():
     from unet_amd.dp import BucketedGradAllReduce, broadcast_parameters
 
     torch.manual_seed(0)
-    model = unet_amd.CondUNet1D(**CONFIG_B)
+    cfg = dict(CONFIG_B, attention_type=args.attention)
+    model = unet_amd.CondUNet1D(**cfg)
     with torch.no_grad():  # the reference zero-initialises outc; give it values so backward is not trivially zero
         model.outc.weight.normal_(0, 0.02)
     model = model.to(dev)
@@ -234,7 +239,8 @@ def main():
         "config": {"workload": "config B: CondUNet1D train.py/LOSO default (base=256, modern 4x dilated k7 + SE, FiLM, "
                                "skip add, BN), 32ch x 4096 windows, 64 windows/GPU, fwd + L1[500:4500] + bwd + "
                                "grad all-reduce + clip 5.0 + AdamW", "windows_per_gpu": B, "params": n_params,
-                   "parallelism": f"dp{world}", "launch": mode, "conditioning": args.conditioning},
+                   "parallelism": f"dp{world}", "launch": mode, "conditioning": args.conditioning,
+                   "attention": args.attention},
         "final_loss": float(loss.item()), "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
         "ms_each_step": [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(args.steps)],
         "model_tflops_algorithmic": value * 3 * GFLOP_PER_WINDOW_FWD / 1e3,
@@ -269,7 +275,7 @@ def main():
                            "avg_launch_us": 1e6 * dom[1] / dom[2], "launches": dom[2], "timing": timing_mode}
         out["kernels"] = kern
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_windows)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_windows, cfg)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -242,14 +242,16 @@ class CrossFrequencyCouplingAttentionV2(nn.Module):
     def forward_nlc(self, x: Tensor) -> Tensor:
         n, t, c = x.shape
         nb, nh, hd = self.n_bands, self.n_heads, self.head_dim
-        bands = self._split_bands(x)
+        # unbind: ONE autograd node whose backward stacks the five band gradients (indexing bands[:, i] per conv
+        # would zero-fill and add a full [N, nb, L, C] tensor for each of the 15 projections)
+        band = self._split_bands(x).unbind(1)
         g1 = ops.geom_conv(1)
 
         def project(conv):
             w = conv.weight.view(nb, c, c, 1)
             b = conv.bias.view(nb, c)
             # band i: its own C x C conv on the strided view bands[:, i]; -> [N, L, C], channel = head * hd + d
-            return [ops.conv(bands[:, i], w[i].permute(2, 0, 1), b[i], g1, t) for i in range(nb)]
+            return [ops.conv(band[i], w[i].permute(2, 0, 1), b[i], g1, t) for i in range(nb)]
 
         q, k, v = project(self.proj_q), project(self.proj_k), project(self.proj_v)
         coupling = F.softmax(self.coupling_weights.float(), dim=-1)
