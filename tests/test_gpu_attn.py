@@ -109,3 +109,36 @@ def test_module_bf16_kernels_close_to_reference(name):
     for k, ref in above_floor(g["grads"]).items():
         bar = 1.8e-1 if ref.numel() <= 25 else 6e-2
         assert rel(grads[k].grad.cpu(), ref) < bar, (k, rel(grads[k].grad.cpu(), ref))
+
+
+def test_self_attention_1d_on_the_flash_kernel():
+    """SelfAttention1D (models.py:75-97) at the config-A bottleneck width, peaked scores (no 1/sqrt(d) in this layer).
+    bf16 on the HIP flash kernels against the module in fp32; the yardstick is the same module in bf16 with torch's
+    own products (bf16 rounding of q and k moves peaked softmaxes whatever evaluates them): the kernels must be
+    within 1.25x of that error + 5e-3, and the output within 2e-2."""
+    from unet_amd.model import SelfAttention1D
+    torch.manual_seed(4)
+    m = SelfAttention1D(512).cuda()
+    with torch.no_grad():
+        m.gamma.fill_(0.8)
+        m.query.weight.mul_(2.0)
+        m.key.weight.mul_(2.0)
+    x = torch.randn(2, 512, 300, device="cuda")
+    g = torch.randn(2, 512, 300, device="cuda")
+
+    def run(inp, flash):
+        m.use_flash = flash
+        m.zero_grad()
+        inp = inp.clone().requires_grad_(True)
+        y = m(inp)
+        (y.float() * g).sum().backward()
+        out = {"y": y.detach().float().cpu(), "dx": inp.grad.float().cpu()}
+        out.update({k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters()})
+        return out
+
+    ref, torch16, flash16 = run(x, False), run(x.bfloat16(), False), run(x.bfloat16(), True)
+    assert rel(flash16["y"], ref["y"]) < 2e-2
+    floor = 1e-5 * max(v.norm().item() for v in ref.values())
+    for k, v in ref.items():
+        if v.norm().item() > floor:
+            assert rel(flash16[k], v) <= 1.25 * rel(torch16[k], v) + 5e-3, (k, rel(flash16[k], v), rel(torch16[k], v))

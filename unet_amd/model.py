@@ -129,8 +129,9 @@ def _norm_act(y: Tensor, norm: nn.Module, act_id: int, want_pool: bool):
 # blocks (parameter layout = the reference's; compute = HIP ops)
 # ---------------------------------------------------------------------------------------------
 class SelfAttention1D(nn.Module):
-    """models.py:75-97.  1x1 projections on the HIP conv kernel; the two batched products and
-    the softmax of this constructor-default-only bottleneck layer use torch (rocBLAS)."""
+    """models.py:75-97.  1x1 projections on the HIP conv kernel; in bf16 the attention itself runs on the flash
+    kernels of csrc/attn.hip (query/key width a multiple of 8, i.e. channels >= 64); fp32 parity runs and narrower
+    layers evaluate softmax(q k^T) v with torch."""
 
     def __init__(self, channels: int, reduction: int = 8):
         super().__init__()
@@ -139,6 +140,7 @@ class SelfAttention1D(nn.Module):
         self.key = nn.Conv1d(channels, channels // reduction, kernel_size=1)
         self.value = nn.Conv1d(channels, channels, kernel_size=1)
         self.gamma = nn.Parameter(torch.zeros(1))
+        self.use_flash = True          # tests switch it off to compare with the torch evaluation in the same dtype
 
     def forward_nlc(self, x: Tensor) -> Tensor:
         g1 = ops.geom_conv(1)
@@ -146,8 +148,16 @@ class SelfAttention1D(nn.Module):
         q = ops.conv(x, self.query.weight.permute(2, 0, 1), self.query.bias, g1, l)
         k = ops.conv(x, self.key.weight.permute(2, 0, 1), self.key.bias, g1, l)
         v = ops.conv(x, self.value.weight.permute(2, 0, 1), self.value.bias, g1, l)
-        att = torch.softmax(torch.bmm(q, k.transpose(1, 2)).float(), dim=-1).to(x.dtype)
-        out = torch.bmm(att, v)
+        dq, rep = q.shape[2], self.channels // q.shape[2]
+        if self.use_flash and x.dtype == torch.bfloat16 and dq % 8 == 0 and dq <= 256 and rep * dq == self.channels:
+            # flash kernel of csrc/attn.hip (one band, no coupling, scale 1): the value channels are split into
+            # `rep` heads of dq channels that all see the same scores, so q and k are tiled across the heads;
+            # no [N, L, L] score tensor, one launch forward, three backward
+            one = torch.ones((1, 1), dtype=torch.float32, device=x.device)
+            out = ops.cfc_attention(q.repeat(1, 1, rep)[None], k.repeat(1, 1, rep)[None], v[None], one, rep, 1.0)
+        else:
+            att = torch.softmax(torch.bmm(q, k.transpose(1, 2)).float(), dim=-1).to(x.dtype)
+            out = torch.bmm(att, v)
         return (x.float() + self.gamma.float() * out.float()).to(x.dtype)  # fp32 so d(gamma) reduces in fp32
 
     def forward(self, x: Tensor) -> Tensor:
