@@ -262,8 +262,11 @@ int unet_overlap_add(int32_t dtype, const void* pred, int32_t n_windows, int32_t
  *   out[n][l][i*c + h*hd + d] = sum_j coupling[i*n_bands + j] * softmax_keys(q_i k_j^T * scale) v_j     (hd = c / n_heads)
  * q, k, v: [n_bands][n][l][c] (band-major stack of the grouped projections, channel = head*hd + d);
  * coupling: n_bands^2 floats on the device (already softmaxed, models.py:428); out: [n][l][n_bands*c].
- * o_pairs [n_bands][n_bands][n][l][c] and lse [n_bands][n_bands][n][n_heads][l] (fp32, log2 domain) are what
- * backward needs; both null for inference.  hd must be a multiple of 8, at most 256.
+ * o_pairs [n_bands][n_bands][n][l][c] (the 25 attention outputs, bf16) and lse [n_bands][n_bands][n][n_heads][l]
+ * (fp32, log2 domain) are what backward needs.  lse may be null (inference).  o_pairs may be null as well: the sum
+ * over j is then kept in registers and no pair output is stored (slower: the second accumulator costs the registers
+ * that keep LDS reads ahead of the MFMAs; and the sum is taken before instead of after the bf16 rounding of each
+ * pair output, so the two modes differ in the last bf16 bit).  hd must be a multiple of 8, at most 256.
  *
  * unet_cfc_attn_bwd: gradients of the same expression.  dout: [n][l][n_bands*c]; dq, dk, dv: [n_bands][n][l][c];
  * dcoupling: n_bands^2 floats (gradient w.r.t. the softmaxed weights; overwritten); delta: scratch of lse's shape. */

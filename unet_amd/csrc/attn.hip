@@ -50,6 +50,7 @@ template <int HDP> struct Cfg {
   static constexpr int DT = HDP / 32;                  // 32-wide tiles over the head dim
   static constexpr int TILE = AT_BK * ROWB;            // bytes of a [64][HDP] tile
   static constexpr int PPW = TILE / 1024 / 4;          // 1 KiB pieces per wave
+  static constexpr int SB = KS < 4 ? KS : 4;           // k-steps per batch of row-read fragments
 };
 
 // chunk swizzle of the LDS images: rows that differ in their low two bits land in different 64-byte groups
@@ -111,7 +112,10 @@ template <int HDP> __device__ __forceinline__ int tr_read_base(int lane, int u) 
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <int HDP>
+// MIX: the coupling-weighted sum over the key/value bands is kept in registers and written to `out` (inference:
+// nothing else is stored).  !MIX (training: every O_ij is stored for backward anyway): no second accumulator, which
+// leaves the registers the compiler needs to keep LDS reads ahead of the MFMAs; cfc_attn_mix_kernel sums the pairs.
+template <int HDP, bool MIX>
 __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK p) {
   typedef Cfg<HDP> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K tile | V tile]
@@ -148,11 +152,14 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK
   const int a0 = row_read_base<HDP>(lane);
   const int vb0 = tr_read_base<HDP>(lane, 0), vb1 = tr_read_base<HDP>(lane, 1);
 
-  f32x16 acc[G::DT], mix[G::DT];
+  f32x16 acc[G::DT], mix[MIX ? G::DT : 1];
 #pragma unroll
   for (int d = 0; d < G::DT; ++d)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { acc[d][e] = 0.f; mix[d][e] = 0.f; }
+    for (int e = 0; e < 16; ++e) {
+      acc[d][e] = 0.f;
+      if (MIX) mix[d][e] = 0.f;
+    }
   float m = -INFINITY, lsum = 0.f;
 
   const int nkb = (p.l + AT_BK - 1) / AT_BK;
@@ -184,13 +191,40 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int e = 0; e < 16; ++e) st[t][e] = 0.f;
+    // fragments are read in batches of SB k-steps, one batch ahead of the MFMAs that consume them
+    // (the MIX variant has no registers to spare: one k-step per batch, V^T fragments read as they are used)
+    constexpr int SBF = MIX ? 1 : G::SB;
+    bf16x8 fk[2][SBF][2];
+    auto load_k = [&](int b, int slot) {
 #pragma unroll
-    for (int s = 0; s < G::KS; ++s)
+      for (int s4 = 0; s4 < SBF; ++s4)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(kt + ((a0 ^ (s << 5)) + t * 32 * G::ROWB));
-        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], st[t], 0, 0, 0);
-      }
+        for (int t = 0; t < 2; ++t)
+          fk[slot][s4][t] = *reinterpret_cast<const bf16x8*>(kt + ((a0 ^ ((b * SBF + s4) << 5)) + t * 32 * G::ROWB));
+    };
+    load_k(0, 0);
+#pragma unroll
+    for (int b = 0; b < G::KS / SBF; ++b) {
+      if (b + 1 < G::KS / SBF) load_k(b + 1, (b + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the reads of the next batch above this batch's MFMAs
+#pragma unroll
+      for (int s4 = 0; s4 < SBF; ++s4)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[b & 1][s4][t], qf[b * SBF + s4], st[t], 0, 0, 0);
+    }
+    // V^T fragments of the first 16 keys: in flight during the softmax arithmetic
+    bf16x8 fv[MIX ? 1 : 2][G::DT];
+    auto load_v = [&](int g, int slot) {
+      const int rowoff = (32 * (g >> 1) + 16 * (g & 1)) * G::ROWB;
+#pragma unroll
+      for (int d = 0; d < G::DT; ++d)
+        fv[slot][d] = tr_pair(vt + ((vb0 ^ (d << 6)) + rowoff), vt + ((vb1 ^ (d << 6)) + rowoff));
+    };
+    if (!MIX) {
+      load_v(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     // ---- online softmax over the keys (registers + the other lane half) ----------------------
     const int key0 = kb * AT_BK;
@@ -207,7 +241,10 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[t][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;
-    const float m_new = fmaxf(m, mx);
+    // lazy rescale: the running maximum only moves when it is exceeded by more than 2^8 (p stays <= 256, far from
+    // any overflow; O, l and lse = m + log2 l are all relative to the same m).  With 32 rows per wave a plain
+    // "new maximum" test fires in almost every tile, and the rescale costs ~400 instructions on the 128 accumulators.
+    const float m_new = mx > m + 8.f ? mx : m;
     if (__any(m_new > m)) {
       const float alpha = __builtin_amdgcn_exp2f(m - m_new);
       lsum *= alpha;
@@ -217,28 +254,31 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK
         for (int e = 0; e < 16; ++e) acc[d][e] *= alpha;
       m = m_new;
     }
+    // ---- P = exp2(S - m), O^T += V^T P^T.  The exponentials of the next 16 keys are issued between the MFMAs
+    // of the current 16 (one wave per SIMD: nothing else would hide them) ----------------------------------------
+    auto exp_one = [&](int t, int e) {
+      const float pe = __builtin_amdgcn_exp2f(fmaf(st[t][e], p.scale_log2, -m));
+      st[t][e] = pe;
+      lsum += pe;
+    };
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int e = 0; e < 8; ++e) exp_one(0, e);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pe = __builtin_amdgcn_exp2f(fmaf(st[t][e], p.scale_log2, -m));
-        st[t][e] = pe;
-        lsum += pe;
-      }
-
-    // ---- O^T += V^T P^T ------------------------------------------------------------------------
+    for (int g = 0; g < 4; ++g) {
+      const int t = g >> 1, s = g & 1, tn = (g + 1) >> 1, sn = (g + 1) & 1;
+      const bf16x8 pb = pack8(st[t], s);
+      if (MIX) load_v(g, 0);
+      else if (g < 3) load_v(g + 1, (g + 1) & 1);
+      if (!MIX) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int d = 0; d < G::DT; ++d) {
+        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[MIX ? 0 : (g & 1)][d], pb, acc[d], 0, 0, 0);
+        if (g < 3) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 pb = pack8(st[t], s);
-        const int rowoff = (32 * t + 16 * s) * G::ROWB;
-#pragma unroll
-        for (int d = 0; d < G::DT; ++d) {
-          const bf16x8 a = tr_pair(vt + ((vb0 ^ (d << 6)) + rowoff), vt + ((vb1 ^ (d << 6)) + rowoff));
-          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, acc[d], 0, 0, 0);
+          for (int x = d * 8 / G::DT; x < (d + 1) * 8 / G::DT; ++x) exp_one(tn, 8 * sn + x);
         }
       }
+    }
 
     // ---- end of a band pair: normalise, keep what backward needs, mix -----------------------------
     if (kb + 1 == nkb) {
@@ -261,7 +301,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            mix[d][4 * e4 + e] = fmaf(acc[d][4 * e4 + e], cw, mix[d][4 * e4 + e]);
+            if (MIX) mix[d][4 * e4 + e] = fmaf(acc[d][4 * e4 + e], cw, mix[d][4 * e4 + e]);
             acc[d][4 * e4 + e] = 0.f;
           }
         }
@@ -275,7 +315,7 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK
     }
   }
 
-  if (row_ok) {
+  if (MIX && row_ok) {
     __bf16* yp = p.out + ((long long)n * p.l + qrow) * ((long long)p.nb * p.c) + (long long)bi * p.c + hoff;
 #pragma unroll
     for (int d = 0; d < G::DT; ++d)
@@ -285,10 +325,37 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK
         if (dd < p.hd) {
           bf16x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (__bf16)mix[d][4 * e4 + e];
+          for (int e = 0; e < 4; ++e) o[e] = (__bf16)mix[MIX ? d : 0][4 * e4 + e];
           *reinterpret_cast<bf16x4*>(yp + dd) = o;
         }
       }
+  }
+}
+
+// out[n][l][i*C + ch] = sum_j coupling[i][j] * O_ij[n][l][ch]   (fp32 sum of the stored bf16 pair outputs, which is
+// what the reference adds up: models.py:452-456).  HBM-bound: nb reads + 1 write per element.
+__global__ __launch_bounds__(AT_THREADS) void cfc_attn_mix_kernel(const AttnK p) {
+  const long long chunks = (long long)p.n * p.l * (p.c >> 3);       // 16-byte chunks of one [N, L, C] slab
+  const int bi = blockIdx.y;
+  const long long slab_all = (long long)p.n * p.l * p.c;
+  float cw[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) cw[j] = j < p.nb ? p.coupling[bi * p.nb + j] : 0.f;
+  for (long long x = (long long)blockIdx.x * AT_THREADS + threadIdx.x; x < chunks; x += (long long)gridDim.x * AT_THREADS) {
+    const long long row = x / (p.c >> 3);
+    const int ch = (int)(x - row * (p.c >> 3)) * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int j = 0; j < p.nb; ++j) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(p.o_pairs + ((long long)bi * p.nb + j) * slab_all + row * p.c + ch);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf((float)v[e], cw[j], acc[e]);
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[e];
+    *reinterpret_cast<bf16x8*>(p.out + row * ((long long)p.nb * p.c) + (long long)bi * p.c + ch) = o;
   }
 }
 
@@ -424,16 +491,40 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_dq_kernel(const AttnK 
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int e = 0; e < 16; ++e) { st[t][e] = 0.f; dp[t][e] = 0.f; }
+    constexpr int SB2 = G::SB < 2 ? G::SB : 2;     // k-steps per batch (K and V fragments: 8 per batch)
+    bf16x8 fk[2][SB2][2], fw[2][SB2][2];
+    auto load_kv = [&](int b, int slot) {
 #pragma unroll
-    for (int s = 0; s < G::KS; ++s)
+      for (int s2 = 0; s2 < SB2; ++s2)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int o = (a0 ^ (s << 5)) + t * 32 * G::ROWB;
-        const bf16x8 ak = *reinterpret_cast<const bf16x8*>(kt + o);
-        const bf16x8 av = *reinterpret_cast<const bf16x8*>(vt + o);
-        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qf[s], st[t], 0, 0, 0);
-        dp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dof[s], dp[t], 0, 0, 0);
-      }
+        for (int t = 0; t < 2; ++t) {
+          const int o = (a0 ^ ((b * SB2 + s2) << 5)) + t * 32 * G::ROWB;
+          fk[slot][s2][t] = *reinterpret_cast<const bf16x8*>(kt + o);
+          fw[slot][s2][t] = *reinterpret_cast<const bf16x8*>(vt + o);
+        }
+    };
+    load_kv(0, 0);
+#pragma unroll
+    for (int b = 0; b < G::KS / SB2; ++b) {
+      if (b + 1 < G::KS / SB2) load_kv(b + 1, (b + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s2 = 0; s2 < SB2; ++s2)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[b & 1][s2][t], qf[b * SB2 + s2], st[t], 0, 0, 0);
+          dp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[b & 1][s2][t], dof[b * SB2 + s2], dp[t], 0, 0, 0);
+        }
+    }
+    bf16x8 ft[2][G::DT];                           // K^T fragments, one group of 16 keys ahead
+    auto load_t = [&](int g, int slot) {
+      const int rowoff = (32 * (g >> 1) + 16 * (g & 1)) * G::ROWB;
+#pragma unroll
+      for (int d = 0; d < G::DT; ++d)
+        ft[slot][d] = tr_pair(kt + ((vb0 ^ (d << 6)) + rowoff), kt + ((vb1 ^ (d << 6)) + rowoff));
+    };
+    load_t(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     const int key0 = kb * AT_BK;
     const bool ragged = key0 + AT_BK > p.l;
 #pragma unroll
@@ -445,17 +536,13 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_dq_kernel(const AttnK 
         st[t][e] = pe * fmaf(dp[t][e], cw, -delta);
       }
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int g = 0; g < 4; ++g) {
+      const bf16x8 db = pack8(st[g >> 1], g & 1);
+      if (g < 3) load_t(g + 1, (g + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 db = pack8(st[t], s);
-        const int rowoff = (32 * t + 16 * s) * G::ROWB;
-#pragma unroll
-        for (int d = 0; d < G::DT; ++d) {
-          const bf16x8 a = tr_pair(kt + ((vb0 ^ (d << 6)) + rowoff), kt + ((vb1 ^ (d << 6)) + rowoff));
-          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, db, acc[d], 0, 0, 0);
-        }
-      }
+      for (int d = 0; d < G::DT; ++d) acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ft[g & 1][d], db, acc[d], 0, 0, 0);
+    }
     if (++kb == nkb) { kb = 0; ++j; }
   }
 
@@ -571,14 +658,41 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_dkv_kernel(const AttnK
     f32x16 st, dp;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+    constexpr int SBK = G::SB < 2 ? G::SB : 2;       // (256 accumulator + 128 operand registers are taken)
+    bf16x8 fq[2][SBK], fd[2][SBK];                   // batches of SBK k-steps, one batch ahead of the MFMAs
+    auto load_qd = [&](int b, int slot) {
 #pragma unroll
-    for (int s = 0; s < G::KS; ++s) {
-      const int o = a0 ^ (s << 5);
-      const bf16x8 aq = *reinterpret_cast<const bf16x8*>(qtile + o);
-      const bf16x8 ad = *reinterpret_cast<const bf16x8*>(dtile + o);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[s], st, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[s], dp, 0, 0, 0);
+      for (int s4 = 0; s4 < SBK; ++s4) {
+        const int o = a0 ^ ((b * SBK + s4) << 5);
+        fq[slot][s4] = *reinterpret_cast<const bf16x8*>(qtile + o);
+        fd[slot][s4] = *reinterpret_cast<const bf16x8*>(dtile + o);
+      }
+    };
+    load_qd(0, 0);
+#pragma unroll
+    for (int b = 0; b < G::KS / SBK; ++b) {
+      if (b + 1 < G::KS / SBK) load_qd(b + 1, (b + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s4 = 0; s4 < SBK; ++s4) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[b & 1][s4], kf[b * SBK + s4], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[b & 1][s4], vf[b * SBK + s4], dp, 0, 0, 0);
+      }
     }
+    // transposed dO / Q fragments in batches of TB head-dim tiles, one batch ahead
+    constexpr int TB = 1, NTB = 2 * (G::DT / TB);     // batches over (k-step s, d)
+    bf16x8 tq[2][TB], td[2][TB];
+    auto load_tt = [&](int b, int slot) {
+      const int s = b / (G::DT / TB), d0 = (b % (G::DT / TB)) * TB;
+#pragma unroll
+      for (int x = 0; x < TB; ++x) {
+        const int o0 = (vb0 ^ ((d0 + x) << 6)) + 16 * s * G::ROWB, o1 = (vb1 ^ ((d0 + x) << 6)) + 16 * s * G::ROWB;
+        td[slot][x] = tr_pair(dtile + o0, dtile + o1);
+        tq[slot][x] = tr_pair(qtile + o0, qtile + o1);
+      }
+    };
+    load_tt(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e4 = 0; e4 < 4; ++e4) {
       const int rl = 32 * par + 8 * e4 + 4 * h;           // local rows rl .. rl+3 live in registers 4*e4 .. 4*e4+3
@@ -592,16 +706,15 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_dkv_kernel(const AttnK
       }
     }
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int b = 0; b < NTB; ++b) {
+      const int s = b / (G::DT / TB), d0 = (b % (G::DT / TB)) * TB;
       const bf16x8 pb = pack8(st, s), db = pack8(dp, s);
-      const int rowoff = 16 * s * G::ROWB;
+      if (b + 1 < NTB) load_tt(b + 1, (b + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int d = 0; d < G::DT; ++d) {
-        const int o0 = (vb0 ^ (d << 6)) + rowoff, o1 = (vb1 ^ (d << 6)) + rowoff;
-        const bf16x8 adT = tr_pair(dtile + o0, dtile + o1);
-        dva[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(adT, pb, dva[d], 0, 0, 0);
-        const bf16x8 aqT = tr_pair(qtile + o0, qtile + o1);
-        dka[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aqT, db, dka[d], 0, 0, 0);
+      for (int x = 0; x < TB; ++x) {
+        dva[d0 + x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(td[b & 1][x], pb, dva[d0 + x], 0, 0, 0);
+        dka[d0 + x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[b & 1][x], db, dka[d0 + x], 0, 0, 0);
       }
     }
     if (it + 1 < total && tid < 128) stats[((it + 1) & 1) * 128 + tid] = stat_next;
@@ -644,7 +757,8 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_dkv_kernel(const AttnK
 }
 
 #define CFC_INSTANTIATE(HDP)                                             \
-  template __global__ void cfc_attn_fwd_kernel<HDP>(const AttnK);       \
+  template __global__ void cfc_attn_fwd_kernel<HDP, true>(const AttnK);  \
+  template __global__ void cfc_attn_fwd_kernel<HDP, false>(const AttnK); \
   template __global__ void cfc_attn_dq_kernel<HDP>(const AttnK);        \
   template __global__ void cfc_attn_dkv_kernel<HDP>(const AttnK);
 CFC_INSTANTIATE(32)
@@ -655,13 +769,22 @@ CFC_INSTANTIATE(256)
 
 template <int HDP> int launch_fwd(const AttnK& p, hipStream_t st) {
   const size_t lds = 4 * (size_t)Cfg<HDP>::TILE;
+  const bool mix = p.o_pairs == nullptr;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cfc_attn_fwd_kernel<HDP>),
+    hipError_t e = hipFuncSetAttribute(mix ? reinterpret_cast<const void*>(&cfc_attn_fwd_kernel<HDP, true>)
+                                           : reinterpret_cast<const void*>(&cfc_attn_fwd_kernel<HDP, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     UNET_REQUIRE(e == hipSuccess, "cfc_attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
   }
   const long long blocks = (long long)p.n * p.nh * p.nb * cdiv(p.l, AT_BQ);
-  hipLaunchKernelGGL(cfc_attn_fwd_kernel<HDP>, dim3((unsigned)blocks), dim3(AT_THREADS), lds, st, p);
+  if (mix) {
+    hipLaunchKernelGGL((cfc_attn_fwd_kernel<HDP, true>), dim3((unsigned)blocks), dim3(AT_THREADS), lds, st, p);
+  } else {
+    hipLaunchKernelGGL((cfc_attn_fwd_kernel<HDP, false>), dim3((unsigned)blocks), dim3(AT_THREADS), lds, st, p);
+    const long long chunks = (long long)p.n * p.l * (p.c >> 3);
+    const unsigned gx = (unsigned)((chunks + AT_THREADS - 1) / AT_THREADS < 4096 ? (chunks + AT_THREADS - 1) / AT_THREADS : 4096);
+    hipLaunchKernelGGL(cfc_attn_mix_kernel, dim3(gx, p.nb), dim3(AT_THREADS), 0, st, p);
+  }
   UNET_LAUNCH_CHECK("cfc_attn_fwd");
   return 0;
 }
@@ -697,13 +820,13 @@ int check_geometry(const char* what, int n, int l, int c, int nh, int nb) {
 
 }  // namespace
 
-// no nulls except o_pairs / lse (both or neither: what backward needs)
+// no nulls except o_pairs / lse
 extern "C" int unet_cfc_attn_fwd(int32_t dtype, const void* q, const void* k, const void* v, const float* coupling,
                                  int32_t n, int32_t l, int32_t c, int32_t n_heads, int32_t n_bands, float scale, void* out,
                                  void* o_pairs, float* lse, void* stream) {
   UNET_REQUIRE(dtype == UNET_BF16, "cfc_attn_fwd: bf16 only (dtype %d)", dtype);
   UNET_REQUIRE(q && k && v && coupling && out, "cfc_attn_fwd: null pointer");
-  UNET_REQUIRE((o_pairs == nullptr) == (lse == nullptr), "cfc_attn_fwd: o_pairs and lse go together");
+  UNET_REQUIRE(o_pairs || !lse, "cfc_attn_fwd: lse without o_pairs");
   UNET_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out) && aligned16(o_pairs),
                "cfc_attn_fwd: pointers must be 16-byte aligned");
   if (check_geometry("cfc_attn_fwd", n, l, c, n_heads, n_bands)) return -1;

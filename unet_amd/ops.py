@@ -814,7 +814,9 @@ def cfc_attn_forward_raw(q: Tensor, k: Tensor, v: Tensor, coupling: Tensor, n_he
         raise TypeError("cfc attention takes contiguous bfloat16 [nb, N, L, C] stacks")
     coupling = coupling.float().contiguous()
     out = torch.empty((n, l, nb * c), dtype=q.dtype, device=q.device)
-    o_pairs = torch.empty((nb, nb, n, l, c), dtype=q.dtype, device=q.device) if keep else None
+    # the pair outputs are stored also when nothing is kept for backward: the kernel variant that sums them in
+    # registers instead is slower (see include/unet_hip.h) and rounds differently from the training path
+    o_pairs = torch.empty((nb, nb, n, l, c), dtype=q.dtype, device=q.device)
     lse = torch.empty((nb, nb, n, n_heads, l), dtype=torch.float32, device=q.device) if keep else None
     check(_lib.load().unet_cfc_attn_fwd(_lib.BF16, _p(q), _p(k), _p(v), _p(coupling), n, l, c, n_heads, nb, float(scale), _p(out),
                                   _p(o_pairs), _p(lse), _stream()), "unet_cfc_attn_fwd")
