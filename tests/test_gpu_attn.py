@@ -67,6 +67,33 @@ def test_kernels_match_fp32_expression(n, l, c, nh, nb):
     assert (out3.float() - out2.float()).abs().max().item() < 4e-2
 
 
+def test_scores_that_outgrow_the_first_tile():
+    """The forward kernel fixes its softmax reference point at the first 64 keys of a band pair and walks the pair a
+    second time when a later score exceeds it by more than 2^32: keys past the first tile that dominate by far."""
+    from unet_amd import ops
+    torch.manual_seed(5)
+    nb, n, l, c, nh = 2, 2, 200, 128, 2
+    q, k, v = (torch.randn(nb, n, l, c, device="cuda").bfloat16() for _ in range(3))
+    k[:, :, 150] *= 60.0                      # one key per band, far outside the first tile's range
+    k[0, :, 70] *= -45.0
+    coupling = torch.softmax(torch.randn(nb, nb, device="cuda"), dim=-1)
+    scale = 1.0 / math.sqrt(c // nh)
+    qr, kr, vr, cr = (t.detach().clone().requires_grad_(True) for t in (q, k, v, coupling))
+    ref = expression(qr, kr, vr, cr, nh, scale)
+    g = torch.randn_like(ref).bfloat16()
+    ref.backward(g.float())
+    qh, kh, vh, ch = (t.detach().clone().requires_grad_(True) for t in (q, k, v, coupling))
+    out = ops.cfc_attention(qh, kh, vh, ch, nh, scale)
+    assert torch.isfinite(out).all()
+    assert (out.float() - ref).abs().max().item() < 4e-2
+    out.backward(g)
+    for name, a, b in (("dq", qh.grad, qr.grad), ("dk", kh.grad, kr.grad), ("dv", vh.grad, vr.grad),
+                       ("dcoupling", ch.grad, cr.grad)):
+        a, b = a.double().cpu(), b.double().cpu()
+        assert torch.isfinite(a).all(), name
+        assert (a - b).norm().item() <= 3e-2 * b.norm().item() + 1e-4, name
+
+
 def test_rejects_what_the_kernel_cannot_do():
     from unet_amd import ops
     q = torch.randn(2, 1, 16, 24, device="cuda").bfloat16()         # head_dim 12: not a multiple of 8

@@ -160,10 +160,15 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK
       acc[d][e] = 0.f;
       if (MIX) mix[d][e] = 0.f;
     }
-  float m = -INFINITY, lsum = 0.f;
+  // Softmax reference point m of a (row, band pair): the row maximum of the pair's FIRST tile, then fixed.  Later
+  // scores may exceed it by up to 2^32 (p and the sums stay far inside fp32; O, l and lse = m + log2 l are all
+  // relative to the same m), so the accumulators -- which live in AGPRs, out of the VALU's reach -- are never
+  // rescaled inside the loop.  A row that does exceed the margin flags the pair, and the whole workgroup walks it
+  // a second time with m = the true row maxima found in the first walk (never seen outside the tests).
+  float m = -INFINITY, lsum = 0.f, mtrue = -INFINITY;
+  int bad = 0;
 
   const int nkb = (p.l + AT_BK - 1) / AT_BK;
-  const int total = p.nb * nkb;
   const unsigned tile_step = (unsigned)AT_BK * p.c * 2;
 
   auto issue = [&](int j, int kb, int buf) {
@@ -174,16 +179,19 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK
   };
 
   issue(0, 0, 0);
-  int j = 0, kb = 0;
-  for (int it = 0; it < total; ++it) {
-    __syncthreads();   // tile `it` has landed (vmcnt(0) + barrier); every wave is done with the other buffer
+  int j = 0, buf = 0;
+  while (j < p.nb) {
+   // the walk over one band pair: nothing but MFMAs touches the accumulators in here
+   for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();   // the tile in `buf` has landed (vmcnt(0) + barrier); every wave is done with the other buffer
     {
       int kb1 = kb + 1, j1 = j;
       if (kb1 == nkb) { kb1 = 0; ++j1; }
-      if (it + 1 < total) issue(j1, kb1, (it + 1) & 1);
+      if (j1 < p.nb) issue(j1, kb1, buf ^ 1);
     }
-    const char* kt = smem + (it & 1) * 2 * G::TILE;
+    const char* kt = smem + buf * 2 * G::TILE;
     const char* vt = kt + G::TILE;
+    buf ^= 1;
 
     // ---- S^T = K Q^T : [64 keys][32 query rows] as two 32x32 tiles --------------------------
     f32x16 st[2];
@@ -241,19 +249,9 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[t][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;
-    // lazy rescale: the running maximum only moves when it is exceeded by more than 2^8 (p stays <= 256, far from
-    // any overflow; O, l and lse = m + log2 l are all relative to the same m).  With 32 rows per wave a plain
-    // "new maximum" test fires in almost every tile, and the rescale costs ~400 instructions on the 128 accumulators.
-    const float m_new = mx > m + 8.f ? mx : m;
-    if (__any(m_new > m)) {
-      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-      lsum *= alpha;
-#pragma unroll
-      for (int d = 0; d < G::DT; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[d][e] *= alpha;
-      m = m_new;
-    }
+    mtrue = fmaxf(mtrue, mx);
+    m = m == -INFINITY ? mx : m;
+    bad |= mx > m + 32.f;
     // ---- P = exp2(S - m), O^T += V^T P^T.  The exponentials of the next 16 keys are issued between the MFMAs
     // of the current 16 (one wave per SIMD: nothing else would hide them) ----------------------------------------
     auto exp_one = [&](int t, int e) {
@@ -280,8 +278,20 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK
       }
     }
 
+   }
     // ---- end of a band pair: normalise, keep what backward needs, mix -----------------------------
-    if (kb + 1 == nkb) {
+    if (nkb > 1 && __syncthreads_or(bad)) {
+      // second walk over this pair (see above): `buf` now names the buffer that holds the prefetched first tile
+      // of the NEXT pair; this pair's first tile replaces it (loads complete in order)
+      issue(j, 0, buf);
+      m = mtrue;
+      lsum = 0.f;
+      bad = 0;
+#pragma unroll
+      for (int d = 0; d < G::DT; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+    } else {
       const float lt = lsum + __shfl_xor(lsum, 32, 64);
       const float inv = 1.f / lt;
       const float cw = p.coupling[bi * p.nb + j] * inv;
@@ -307,11 +317,9 @@ __global__ __launch_bounds__(AT_THREADS, 1) void cfc_attn_fwd_kernel(const AttnK
         }
       }
       m = -INFINITY;
+      mtrue = -INFINITY;
       lsum = 0.f;
-      kb = 0;
       ++j;
-    } else {
-      ++kb;
     }
   }
 
