@@ -36,7 +36,7 @@ struct AttnK {
   float* lse;                // [nb][nb][N][nh][L] or null; log2 domain: p = exp2(s*scale_log2 - lse)
   // backward only
   const __bf16* dout;        // [N][L][nb*C]
-  const float* delta;        // [nb][nb][N][nh][L]
+  float* delta;              // [nb][nb][N][nh][L]: written by rowdot, read by dQ and dK/dV
   __bf16 *dq, *dk, *dv;      // [nb][N][L][C]
   int n, l, c, nh, nb, hd;
   float scale, scale_log2;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(AT_THREADS) void cfc_attn_rowdot_kernel(const AttnK
     if (lane < p.nh) {
       float r = 0.f;
       for (int k = 0; k < cph; ++k) r += part[wave][lane * cph + k];
-      const_cast<float*>(p.delta)[(((long long)pair * p.n + n) * p.nh + lane) * p.l + row] = cw * r;
+      p.delta[(((long long)pair * p.n + n) * p.nh + lane) * p.l + row] = cw * r;
       tot += r;
     }
     __builtin_amdgcn_wave_barrier();
