@@ -72,6 +72,46 @@ def main():
         flops = geom.alg_flops(n, l_out, cout, cin)
         execf = flops / geom.alg_scale
         kinds = ["fwd", "dgrad", "wgrad"] if args.kind == "all" else [args.kind]
+        if args.kind == "pair":      # data-grad + weight-grad of one layer: back to back vs on two streams
+            gd, src = geom.dgrad()
+            wpt = ops.pack_weights(w, ops._dt(x), transpose=True, tap_src=src, n_taps=geom.n_taps, row_lo=0, rows=cin,
+                                   c1=cout, c2=0)
+            d = ops._desc(geom, x, None, dy, None)
+            ws_bytes = lib.unet_conv1d_wgrad_workspace_bytes(C.byref(d))
+            ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=dev)
+            dw = torch.empty((geom.n_taps, cout, cin), dtype=torch.float32, device=dev)
+            dgrad = lambda: ops.conv_forward_raw(gd, dy, None, wpt, None, None, l_in, cin)
+            wgrad = lambda: _lib.check(lib.unet_conv1d_wgrad(C.byref(d), ops._p(x), None, ops._p(dy), ops._p(dw), ops._p(ws),
+                                                             ws_bytes, ops._stream()), "wgrad")
+            side = torch.cuda.Stream()
+            main_s = torch.cuda.current_stream()
+
+            def both_seq():
+                dgrad()
+                wgrad()
+
+            def both_conc():
+                side.wait_stream(main_s)
+                with torch.cuda.stream(side):
+                    wgrad()
+                dgrad()
+                main_s.wait_stream(side)
+
+            res = {}
+            for label, fn in (("seq", both_seq), ("conc", both_conc)):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                res[label] = e0.elapsed_time(e1) * 1e3 / args.iters
+            print(f"{name:9s} dgrad+wgrad  sequential {res['seq']:8.1f} us   two streams {res['conc']:8.1f} us "
+                  f"({100 * (res['conc'] / res['seq'] - 1):+.1f} %)", flush=True)
+            continue
         for k in kinds:
             if k == "fwd":
                 wp = ops.pack_weights(w, ops._dt(x), transpose=False, tap_src=None, n_taps=geom.n_taps, row_lo=0,
