@@ -246,6 +246,37 @@ def cross_freq_v2(sd: SD, pfx: str, x: Tensor, n_heads: int = 4, sample_rate: fl
     return x + sd[pfx + "gate"] * out
 
 
+def cross_freq_v1(sd: SD, pfx: str, x: Tensor, n_heads: int = 4, sample_rate: float = 1000.0, chunk_size: int = 256) -> Tensor:
+    """CrossFrequencyCouplingAttention.forward (models.py:175-220), the chunked V1 module: per-band Conv1d 1x1
+    projections (band_q/k/v ModuleLists), attention restricted to chunks of `chunk_size` positions (a query attends
+    to the keys of its own chunk only; the last chunk may be shorter), outputs mixed by softmax(coupling_weights),
+    1x1 out_proj, gated residual."""
+    B, C, T = x.shape
+    nb, hd = len(CFC_BANDS), C // n_heads
+    freqs = torch.fft.rfftfreq(T, d=1.0 / sample_rate)
+    xf = torch.fft.rfft(x.float(), dim=-1)
+    bands = [torch.fft.irfft(xf * (torch.sigmoid((freqs - lo) / 2) * torch.sigmoid((hi - freqs) / 2))[None, None], n=T, dim=-1)
+             .to(x.dtype) for lo, hi in CFC_BANDS]
+    proj = lambda n, i: F.conv1d(bands[i], sd[f"{pfx}{n}.{i}.weight"], sd[f"{pfx}{n}.{i}.bias"]) \
+        .reshape(B, n_heads, hd, T).transpose(2, 3)                                   # [B, heads, T, hd]
+    coupling = torch.softmax(sd[pfx + "coupling_weights"], dim=-1)
+    outs = []
+    for i in range(nb):
+        q = proj("band_q", i)
+        acc = 0
+        for j in range(nb):
+            k, v = proj("band_k", j), proj("band_v", j)
+            chunks = []
+            for c0 in range(0, T, chunk_size):
+                c1 = min(c0 + chunk_size, T)
+                a = torch.softmax(torch.matmul(q[:, :, c0:c1], k[:, :, c0:c1].transpose(-2, -1)) / math.sqrt(hd), dim=-1)
+                chunks.append(torch.matmul(a, v[:, :, c0:c1]))
+            acc = acc + coupling[i, j] * torch.cat(chunks, dim=2)
+        outs.append(acc.transpose(2, 3).reshape(B, C, T))
+    out = F.conv1d(torch.cat(outs, 1), sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"])
+    return x + sd[pfx + "gate"] * out
+
+
 def adaptive_scale(sd: SD, pfx: str, x: Tensor, raw: Tensor) -> Tensor:
     """models.py:2043-2068 (scalar SessionAdaptiveScaling)."""
     st = torch.cat([raw.mean(dim=-1), raw.std(dim=-1)], dim=-1)
@@ -295,8 +326,10 @@ def forward(sd: SD, cfg: dict, ob: Tensor, odor_ids: Optional[Tensor] = None,
             h = self_attention(sd, "mid.2.", h)
         elif cfg["attention_type"] == "cross_freq_v2":
             h = cross_freq_v2(sd, "mid.2.", h, cfg.get("n_heads", 4), cfg.get("sampling_rate", 1000.0))
+        elif cfg["attention_type"] == "cross_freq":
+            h = cross_freq_v1(sd, "mid.2.", h, cfg.get("n_heads", 4), cfg.get("sampling_rate", 1000.0))
         else:
-            raise NotImplementedError("oracle covers attention_type in {none, basic, cross_freq_v2}")
+            raise NotImplementedError("oracle covers attention_type in {none, basic, cross_freq, cross_freq_v2}")
         j = 3
     else:
         j = 2
@@ -430,6 +463,17 @@ def init_state_dict(cfg: dict, seed: int = 0) -> SD:
         for n in ("proj_q", "proj_k", "proj_v"):
             sd[f"mid.2.{n}.weight"] = rnd(nb * cb, cb, 1)
             sd[f"mid.2.{n}.bias"] = rnd(nb * cb, scale=0.1)
+        sd["mid.2.out_proj.weight"] = rnd(cb, nb * cb, 1)
+        sd["mid.2.out_proj.bias"] = rnd(cb, scale=0.1)
+        sd["mid.2.coupling_weights"] = rnd(nb, nb, scale=0.5)
+        sd["mid.2.gate"] = torch.full((1,), 0.3)
+        j = 3
+    elif has_attn and cfg["attention_type"] == "cross_freq":
+        nb = len(CFC_BANDS)
+        for n in ("band_q", "band_k", "band_v"):
+            for i in range(nb):
+                sd[f"mid.2.{n}.{i}.weight"] = rnd(cb, cb, 1)
+                sd[f"mid.2.{n}.{i}.bias"] = rnd(cb, scale=0.1)
         sd["mid.2.out_proj.weight"] = rnd(cb, nb * cb, 1)
         sd["mid.2.out_proj.bias"] = rnd(cb, scale=0.1)
         sd["mid.2.coupling_weights"] = rnd(nb, nb, scale=0.5)

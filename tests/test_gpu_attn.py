@@ -10,7 +10,7 @@ import math
 import pytest
 import torch
 
-from tests.test_oracle_attn import CASES, above_floor, load_case, rel
+from tests.test_oracle_attn import CASES, CASES_V1, GOLD_V1, above_floor, load_case, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -177,3 +177,62 @@ def test_self_attention_1d_on_the_flash_kernel():
     for k, v in ref.items():
         if v.norm().item() > floor:
             assert rel(flash16[k], v) <= 1.25 * rel(torch16[k], v) + 5e-3, (k, rel(flash16[k], v), rel(torch16[k], v))
+
+
+def _module_v1(g):
+    from unet_amd.model import CrossFrequencyCouplingAttention
+    m = CrossFrequencyCouplingAttention(g["c"], n_heads=g["nh"], chunk_size=g["cs"]).cuda()
+    m.load_state_dict(g["sd"], strict=True)
+    return m
+
+
+@pytest.mark.parametrize("name", CASES_V1)
+def test_v1_module_fp32_matches_reference(name):
+    """attention_type="cross_freq" (models.py:100-224): chunks as batch items; fp32 on torch products."""
+    g = load_case(name, GOLD_V1)
+    m = _module_v1(g)
+    x = g["x"].cuda().requires_grad_(True)
+    y = m(x)
+    assert rel(y.detach().cpu(), g["y"]) < 1e-4
+    (y * g["gy"].cuda()).sum().backward()
+    assert rel(x.grad.cpu(), g["dx"]) < 1e-3
+    grads = dict(m.named_parameters())
+    for k, ref in above_floor(g["grads"]).items():
+        assert rel(grads[k].grad.cpu(), ref) < 1e-3, k
+
+
+@pytest.mark.parametrize("name", CASES_V1)
+def test_v1_module_bf16_kernels_close_to_reference(name):
+    """Same bars as the V2 module: output <= 2e-2, gradients <= 6e-2 (3x for coupling_weights / gate)."""
+    g = load_case(name, GOLD_V1)
+    m = _module_v1(g)
+    x = g["x"].cuda().bfloat16().requires_grad_(True)
+    y = m(x)
+    assert y.dtype == torch.bfloat16
+    assert rel(y.detach().float().cpu(), g["y"]) < 2e-2
+    (y.float() * g["gy"].cuda()).sum().backward()
+    assert rel(x.grad.float().cpu(), g["dx"]) < 6e-2
+    grads = dict(m.named_parameters())
+    for k, ref in above_floor(g["grads"]).items():
+        bar = 1.8e-1 if ref.numel() <= 25 else 6e-2
+        assert rel(grads[k].grad.cpu(), ref) < bar, (k, rel(grads[k].grad.cpu(), ref))
+
+
+def test_model_with_v1_attention_builds_and_steps():
+    """CondUNet1D(attention_type="cross_freq") against the oracle on the same seeded weights (fp32 <= 1e-3)."""
+    import unet_amd
+    from oracle import condunet_oracle as O
+    cfg = dict(in_channels=8, out_channels=8, base=16, emb_dim=16, attention_type="cross_freq")
+    model = unet_amd.CondUNet1D(**cfg).cuda()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        sd["mid.2.gate"].fill_(0.5)
+        sd["outc.weight"].normal_(0, 0.05)
+    model.load_state_dict(sd)
+    model.train()
+    gen = torch.Generator().manual_seed(2)
+    ob = torch.randn(2, 8, 512, generator=gen)
+    ids = torch.tensor([1, 3])
+    pred = model(ob.cuda(), ids.cuda())
+    ref = O.forward(sd, cfg, ob, training=True, odor_ids=ids)
+    assert rel(pred.detach().cpu(), ref.detach()) < 1e-3

@@ -164,6 +164,28 @@ class SelfAttention1D(nn.Module):
         return _as_ncl(self.forward_nlc(_to_nlc(x)))
 
 
+def _band_pair_attention(q: Tensor, k: Tensor, v: Tensor, coupling: Tensor, n_heads: int, scale: float) -> Tensor:
+    """q, k, v: [nb, M, l, C] stacks of the per-band projections -> [M, l, nb*C]:
+    out[:, :, i*C + h*hd + d] = sum_j coupling[i, j] * softmax(q_i k_j^T * scale) v_j   (models.py:431-462 / 191-216).
+    bf16: ONE launch of the band-pair flash kernel (csrc/attn.hip; three launches backward).  fp32 (parity runs) and
+    head sizes the kernel does not take: the same products with ``scaled_dot_product_attention``."""
+    nb, m, l, c = q.shape
+    hd = c // n_heads
+    if q.dtype == torch.bfloat16 and hd % 8 == 0 and hd <= 256:
+        return ops.cfc_attention(q.contiguous(), k.contiguous(), v.contiguous(), coupling, n_heads, scale)
+    sp = lambda z: z.reshape(nb, m, l, n_heads, hd).transpose(2, 3)                    # [nb, M, heads, l, hd]
+    qs, ks, vs = sp(q), sp(k), sp(v)
+    outs = []
+    for i in range(nb):
+        acc = None
+        for j in range(nb):
+            a = F.scaled_dot_product_attention(qs[i], ks[j], vs[j], dropout_p=0.0, is_causal=False, scale=scale)
+            a = a.float() * coupling[i, j]
+            acc = a if acc is None else acc + a
+        outs.append(acc.transpose(1, 2).reshape(m, l, c))                               # channel = head * hd + d
+    return torch.cat(outs, dim=2).to(q.dtype)
+
+
 class CrossFrequencyCouplingAttentionV2(nn.Module):
     """models.py:227-474 (``attention_type="cross_freq_v2"``, the phase-four / phase-five default): FFT band split,
     grouped 1x1 q/k/v projections per band, every query band attends to every key/value band, outputs mixed by
@@ -265,22 +287,7 @@ class CrossFrequencyCouplingAttentionV2(nn.Module):
 
         q, k, v = project(self.proj_q), project(self.proj_k), project(self.proj_v)
         coupling = F.softmax(self.coupling_weights.float(), dim=-1)
-        if x.dtype == torch.bfloat16 and hd % 8 == 0 and hd <= 256:
-            # all nb x nb products, their coupling-weighted sum and the band concatenation in one HIP launch
-            cat = ops.cfc_attention(torch.stack(q), torch.stack(k), torch.stack(v), coupling, nh, self.scale)
-            out = ops.conv(cat, self.out_proj.weight.permute(2, 0, 1), self.out_proj.bias, g1, t)
-            return (x.float() + self.gate.float() * out.float()).to(x.dtype)
-        # fp32 (parity runs): the same products through torch
-        q, k, v = ([a.view(n, t, nh, hd).transpose(1, 2) for a in z] for z in (q, k, v))
-        outs = []
-        for i in range(nb):
-            acc = None
-            for j in range(nb):
-                a = F.scaled_dot_product_attention(q[i], k[j], v[j], dropout_p=0.0, is_causal=False)
-                a = a.float() * coupling[i, j]
-                acc = a if acc is None else acc + a
-            outs.append(acc.transpose(1, 2).reshape(n, t, c))                          # channel = head * hd + d
-        cat = torch.cat(outs, dim=2).to(x.dtype)                                       # [N, L, nb*C]
+        cat = _band_pair_attention(torch.stack(q), torch.stack(k), torch.stack(v), coupling, nh, self.scale)
         out = ops.conv(cat, self.out_proj.weight.permute(2, 0, 1), self.out_proj.bias, g1, t)
         return (x.float() + self.gate.float() * out.float()).to(x.dtype)
 
@@ -290,6 +297,61 @@ class CrossFrequencyCouplingAttentionV2(nn.Module):
     def extra_repr(self) -> str:
         band_str = ", ".join(f"{l}-{h}Hz" for l, h in self.bands)
         return f"channels={self.channels}, n_heads={self.n_heads}, flash={self.enable_flash}, bands=[{band_str}]"
+
+
+class CrossFrequencyCouplingAttention(CrossFrequencyCouplingAttentionV2):
+    """models.py:100-224 (``attention_type="cross_freq"``), the chunked V1 module: one Conv1d 1x1 per band and
+    projection (``band_q / band_k / band_v`` ModuleLists: the reference's state-dict keys), and a query attends to
+    the keys of its own chunk of ``chunk_size`` positions only (the last chunk may be shorter).  A chunk is a batch
+    item of the same band-pair kernels: [N, L, C] -> [N * L/chunk, chunk, C] is a view when chunk divides L."""
+
+    def __init__(self, channels: int, n_heads: int = 4, sample_rate: float = 1000.0, bands=None, chunk_size: int = 256):
+        nn.Module.__init__(self)
+        self.channels = channels
+        self.n_heads = n_heads
+        self.head_dim = channels // n_heads
+        self.sample_rate = sample_rate
+        self.chunk_size = chunk_size
+        if bands is None:
+            bands = [(1, 4), (4, 8), (8, 12), (12, 30), (30, 80)]
+        self.bands = bands
+        self.n_bands = len(bands)
+        self.band_q = nn.ModuleList([nn.Conv1d(channels, channels, 1) for _ in bands])
+        self.band_k = nn.ModuleList([nn.Conv1d(channels, channels, 1) for _ in bands])
+        self.band_v = nn.ModuleList([nn.Conv1d(channels, channels, 1) for _ in bands])
+        self.out_proj = nn.Conv1d(channels * self.n_bands, channels, 1)
+        self.coupling_weights = nn.Parameter(torch.ones(self.n_bands, self.n_bands) / self.n_bands)
+        self.gate = nn.Parameter(torch.zeros(1))
+        self._filters_cache: Optional[Tensor] = None
+        self._cache_len: int = 0
+        self._filters_on = {}
+        self.scale = 1.0 / math.sqrt(self.head_dim)
+
+    def forward_nlc(self, x: Tensor) -> Tensor:
+        n, t, c = x.shape
+        nb, nh, cs = self.n_bands, self.n_heads, self.chunk_size
+        band = self._split_bands(x).unbind(1)
+        g1 = ops.geom_conv(1)
+        project = lambda convs: torch.stack([ops.conv(band[i], convs[i].weight.permute(2, 0, 1), convs[i].bias, g1, t)
+                                             for i in range(nb)])                      # [nb, N, L, C]
+        q, k, v = project(self.band_q), project(self.band_k), project(self.band_v)
+        coupling = F.softmax(self.coupling_weights.float(), dim=-1)
+        full = (t // cs) * cs
+        parts = []
+        if full:
+            chunked = lambda z: z[:, :, :full].reshape(nb, n * (full // cs), cs, c)
+            a = _band_pair_attention(chunked(q), chunked(k), chunked(v), coupling, nh, self.scale)
+            parts.append(a.view(n, full, nb * c))
+        if full < t:
+            tail = lambda z: z[:, :, full:]
+            parts.append(_band_pair_attention(tail(q), tail(k), tail(v), coupling, nh, self.scale))
+        cat = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+        out = ops.conv(cat, self.out_proj.weight.permute(2, 0, 1), self.out_proj.bias, g1, t)
+        return (x.float() + self.gate.float() * out.float()).to(x.dtype)
+
+    def extra_repr(self) -> str:
+        band_str = ", ".join(f"{l}-{h}Hz" for l, h in self.bands)
+        return f"channels={self.channels}, chunk_size={self.chunk_size}, bands=[{band_str}]"
 
 
 class FiLM(nn.Module):
@@ -734,8 +796,7 @@ class CondUNet1D(nn.Module):
         if attention_type == "cross_freq_v2":
             return CrossFrequencyCouplingAttentionV2(channels, n_heads=self.n_heads)
         if attention_type == "cross_freq":
-            raise NotImplementedError("attention_type='cross_freq' (the chunked V1 module) is not built; "
-                                      "'cross_freq_v2' is (SURVEY.md 8f N3)")
+            return CrossFrequencyCouplingAttention(channels, n_heads=self.n_heads)
         raise ValueError(f"Unknown attention_type: {attention_type}. Available: none, basic, cross_freq, cross_freq_v2")
 
     def set_gradient_checkpointing(self, enable: bool = True):
