@@ -274,20 +274,13 @@ class CrossFrequencyCouplingAttentionV2(nn.Module):
     def forward_nlc(self, x: Tensor) -> Tensor:
         n, t, c = x.shape
         nb, nh, hd = self.n_bands, self.n_heads, self.head_dim
-        # unbind: ONE autograd node whose backward stacks the five band gradients (indexing bands[:, i] per conv
-        # would zero-fill and add a full [N, nb, L, C] tensor for each of the 15 projections)
-        band = self._split_bands(x).unbind(1)
         g1 = ops.geom_conv(1)
-
-        def project(conv):
-            w = conv.weight.view(nb, c, c, 1)
-            b = conv.bias.view(nb, c)
-            # band i: its own C x C conv on the strided view bands[:, i]; -> [N, L, C], channel = head * hd + d
-            return [ops.conv(band[i], w[i].permute(2, 0, 1), b[i], g1, t) for i in range(nb)]
-
-        q, k, v = project(self.proj_q), project(self.proj_k), project(self.proj_v)
+        # the grouped Conv1d is nb independent C x C convs; one autograd node runs all 15 on strided views of the
+        # band tensor and writes the [nb, N, L, C] stacks the attention kernels read (channel = head * hd + d)
+        wb = lambda conv: (conv.weight.view(nb, c, c), conv.bias.view(nb, c))
+        q, k, v = ops.band_project(self._split_bands(x), *wb(self.proj_q), *wb(self.proj_k), *wb(self.proj_v))
         coupling = F.softmax(self.coupling_weights.float(), dim=-1)
-        cat = _band_pair_attention(torch.stack(q), torch.stack(k), torch.stack(v), coupling, nh, self.scale)
+        cat = _band_pair_attention(q, k, v, coupling, nh, self.scale)
         out = ops.conv(cat, self.out_proj.weight.permute(2, 0, 1), self.out_proj.bias, g1, t)
         return (x.float() + self.gate.float() * out.float()).to(x.dtype)
 
@@ -330,11 +323,9 @@ class CrossFrequencyCouplingAttention(CrossFrequencyCouplingAttentionV2):
     def forward_nlc(self, x: Tensor) -> Tensor:
         n, t, c = x.shape
         nb, nh, cs = self.n_bands, self.n_heads, self.chunk_size
-        band = self._split_bands(x).unbind(1)
         g1 = ops.geom_conv(1)
-        project = lambda convs: torch.stack([ops.conv(band[i], convs[i].weight.permute(2, 0, 1), convs[i].bias, g1, t)
-                                             for i in range(nb)])                      # [nb, N, L, C]
-        q, k, v = project(self.band_q), project(self.band_k), project(self.band_v)
+        wb = lambda convs: (torch.stack([m.weight[:, :, 0] for m in convs]), torch.stack([m.bias for m in convs]))
+        q, k, v = ops.band_project(self._split_bands(x), *wb(self.band_q), *wb(self.band_k), *wb(self.band_v))
         coupling = F.softmax(self.coupling_weights.float(), dim=-1)
         full = (t // cs) * cs
         parts = []

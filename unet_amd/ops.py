@@ -255,9 +255,16 @@ def pack_weights(w: Tensor, dtype: int, *, transpose: bool, tap_src: Optional[Se
 
 
 def conv_forward_raw(geom: ConvGeom, x1: Tensor, x2: Optional[Tensor], w_packed: Tensor, bias: Optional[Tensor],
-                     res: Optional[Tensor], l_out: int, c_out: int, act: int = 0) -> Tensor:
+                     res: Optional[Tensor], l_out: int, c_out: int, act: int = 0, out: Optional[Tensor] = None) -> Tensor:
+    """``out``: write into this [N, l_out, c_out] tensor (any batch / row pitch with unit channel stride) instead of a
+    new one -- how a group of convs fills one buffer without a gather afterwards."""
     lib = _lib.load()
-    y = torch.empty((x1.shape[0], l_out, c_out), dtype=x1.dtype, device=x1.device)
+    if out is not None:
+        if tuple(out.shape) != (x1.shape[0], l_out, c_out) or out.dtype != x1.dtype or out.stride(2) != 1:
+            raise ValueError(f"out {tuple(out.shape)}/{out.dtype} does not fit [{x1.shape[0]}, {l_out}, {c_out}]/{x1.dtype}")
+        y = out
+    else:
+        y = torch.empty((x1.shape[0], l_out, c_out), dtype=x1.dtype, device=x1.device)
     d = _desc(geom, x1, x2, y, res, act)
     with _Timed("conv_fwd", geom.alg_flops(d.n, l_out, c_out, d.c1 + d.c2)):
         check(lib.unet_conv1d_fwd(C.byref(d), _p(x1), _p(x2), _p(w_packed), _p(bias), _p(res), _p(y), _stream()),
@@ -281,13 +288,13 @@ def conv_wgrad_raw(geom: ConvGeom, x1: Tensor, x2: Optional[Tensor], dy: Tensor,
 
 
 def conv_dgrad_raw(geom: ConvGeom, wf: Tensor, dy: Tensor, l_in: int, row_lo: int, rows: int,
-                   res: Optional[Tensor] = None) -> Tensor:
+                   res: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
     """dx[:, :, row_lo:row_lo+rows] of the conv (wf: fp32 [J, Cout, Ctot]); ``res`` is added in the epilogue, which
     is how a second gradient path into the same tensor is merged without an extra pass."""
     gd, src = geom.dgrad()
     j, c_out, _ = wf.shape
     wp = pack_weights(wf, _dt(dy), transpose=True, tap_src=src, n_taps=j, row_lo=row_lo, rows=rows, c1=c_out, c2=0)
-    return conv_forward_raw(gd, dy, None, wp, None, res, l_in, rows)
+    return conv_forward_raw(gd, dy, None, wp, None, res, l_in, rows, out=out)
 
 
 class ConvFn(torch.autograd.Function):
@@ -854,3 +861,55 @@ class CfcAttnFn(torch.autograd.Function):
 def cfc_attention(q: Tensor, k: Tensor, v: Tensor, coupling: Tensor, n_heads: int, scale: float) -> Tensor:
     """q, k, v: [nb, N, L, C] bf16 stacks of the per-band projections; coupling: [nb, nb] softmaxed weights."""
     return CfcAttnFn.apply(q, k, v, coupling, n_heads, scale)
+
+
+class BandProjectFn(torch.autograd.Function):
+    """The per-band 1x1 q / k / v projections of the cross-frequency attention (models.py:420-426 grouped Conv1d,
+    models.py:193-199 per-band Conv1d) as one autograd node: bands [N, nb, L, C] -> three [nb, N, L, C] stacks
+    written in place by the conv kernel (no gather), and backward sums the three data-gradients of a band in the
+    conv epilogue (``res``) straight into its slice of d(bands) (no zero-fill, no adds).
+    w*: [nb, C, C] (out, in), b*: [nb, C]."""
+
+    @staticmethod
+    def forward(ctx, bands, wq, bq, wk, bk, wv, bv):
+        _need_cuda(bands)
+        n, nb, l, c = bands.shape
+        if bands.stride(3) != 1:
+            bands = bands.contiguous()
+        g1 = geom_conv(1)
+        dt = _dt(bands)
+        outs, wfs = [], []
+        for w, b in ((wq, bq), (wk, bk), (wv, bv)):
+            wf = w.detach().float()
+            out = torch.empty((nb, n, l, c), dtype=bands.dtype, device=bands.device)
+            for i in range(nb):
+                wp = pack_weights(wf[i][None], dt, transpose=False, tap_src=None, n_taps=1, row_lo=0, rows=c, c1=c, c2=0)
+                conv_forward_raw(g1, bands[:, i], None, wp, _f32c(b[i]), None, l, c, out=out[i])
+            outs.append(out)
+            wfs.append(wf)
+        ctx.save_for_backward(bands, *wfs)
+        ctx.w_dtype = wq.dtype
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        bands, wfq, wfk, wfv = ctx.saved_tensors
+        n, nb, l, c = bands.shape
+        g1 = geom_conv(1)
+        grads = [g.contiguous() for g in (dq, dk, dv)]
+        need_x = ctx.needs_input_grad[0]
+        dbands = torch.empty_like(bands) if need_x else None
+        dws, dbs = [], []
+        for p, (g, wf) in enumerate(zip(grads, (wfq, wfk, wfv))):
+            dws.append(torch.stack([conv_wgrad_raw(g1, bands[:, i], None, g[i], c)[0] for i in range(nb)]).to(ctx.w_dtype))
+            dbs.append(torch.stack([colsum(g[i]) for i in range(nb)]))
+        if need_x:
+            for i in range(nb):
+                acc = conv_dgrad_raw(g1, wfq[i][None], grads[0][i], l, 0, c)
+                acc = conv_dgrad_raw(g1, wfk[i][None], grads[1][i], l, 0, c, res=acc)
+                conv_dgrad_raw(g1, wfv[i][None], grads[2][i], l, 0, c, res=acc, out=dbands[:, i])
+        return dbands, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2]
+
+
+def band_project(bands: Tensor, wq, bq, wk, bk, wv, bv):
+    return BandProjectFn.apply(bands, wq, bq, wk, bk, wv, bv)
