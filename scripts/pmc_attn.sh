@@ -13,3 +13,8 @@ run() { # name counters...
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT && \
 run sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_WAVES
 echo pmc-done
+# HBM traffic (separate passes; FETCH_SIZE / WRITE_SIZE in the guide's units and corrections) and L2 hit rate
+if [ "$2" = "mem" ]; then
+  run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum && run fetch FETCH_SIZE && run write WRITE_SIZE
+  echo pmc-mem-done
+fi
