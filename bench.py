@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="windows per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-windows", type=int, default=16, help="windows per CPU-baseline step (2 steps are timed)")
+    ap.add_argument("--cpu-windows", type=int, default=16, help="windows per CPU-baseline step (3 steps are timed)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--conditioning", default="odor_onehot", choices=["odor_onehot", "spectro_temporal"],
                     help="spectro_temporal: the SpectroTemporalEncoder (train.py --conditioning default) runs inside the "
@@ -86,7 +86,7 @@ def cpu_baseline(n_windows: int, cfg=None):
     ob = torch.randn(n_windows, 32, T, generator=g)
     tgt = torch.randn(n_windows, 32, T, generator=g)
     ids = torch.zeros(n_windows, dtype=torch.long)
-    reps = 2
+    reps = 3
     t0 = time.perf_counter()
     for _ in range(reps):
         loss = O.train_step_loss(run_sd, cfg, ob, tgt, odor_ids=ids)
