@@ -94,6 +94,41 @@ def test_scores_that_outgrow_the_first_tile():
         assert (a - b).norm().item() <= 3e-2 * b.norm().item() + 1e-4, name
 
 
+def test_config_b_bottleneck_size_properties():
+    """At the config-B bottleneck shape (C=1024, 4 heads x 256, L=1024, 5 bands; 8 windows), where the fp32 expression is
+    too slow to be the checker: (a) with a one-hot coupling matrix band i is plain attention(q_i, k_i, v_i) -- checked
+    against torch's own bf16 attention; (b) the output does not depend on the order of the keys (another walk over the
+    tiles, same sums); (c) gradients are finite and dq/dk/dv of the identity-coupled case match autograd through torch's
+    attention (<= 3e-2 relative L2)."""
+    from unet_amd import ops
+    import torch.nn.functional as F
+    torch.manual_seed(11)
+    nb, n, l, c, nh = 5, 8, 1024, 1024, 4
+    hd = c // nh
+    q, k, v = (torch.randn(nb, n, l, c, device="cuda").bfloat16() for _ in range(3))
+    scale = 1.0 / math.sqrt(hd)
+    eye = torch.eye(nb, device="cuda")
+    qh, kh, vh = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+    out = ops.cfc_attention(qh, kh, vh, eye, nh, scale)                                  # [N, L, nb*C]
+    g = torch.randn_like(out)
+    out.backward(g)
+    sp = lambda t: t.view(nb, n, l, nh, hd).transpose(2, 3)                              # [nb, N, nh, L, hd]
+    qr, kr, vr = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(sp(qr), sp(kr), sp(vr), scale=scale)            # bf16, per band
+    ref_cat = ref.transpose(2, 3).reshape(nb, n, l, c).permute(1, 2, 0, 3).reshape(n, l, nb * c)
+    assert (out.float() - ref_cat.float()).abs().max().item() < 3e-2
+    ref_cat.backward(g)
+    for name, a, b in (("dq", qh.grad, qr.grad), ("dk", kh.grad, kr.grad), ("dv", vh.grad, vr.grad)):
+        assert torch.isfinite(a).all(), name
+        assert rel(a.float().cpu(), b.float().cpu()) < 3e-2, name
+    perm = torch.randperm(l, device="cuda")
+    coupling = torch.softmax(torch.randn(nb, nb, device="cuda"), dim=-1)
+    with torch.no_grad():
+        o1 = ops.cfc_attention(q, k, v, coupling, nh, scale)
+        o2 = ops.cfc_attention(q, k[:, :, perm].contiguous(), v[:, :, perm].contiguous(), coupling, nh, scale)
+    assert (o1.float() - o2.float()).abs().max().item() < 2e-2
+
+
 def test_rejects_what_the_kernel_cannot_do():
     from unet_amd import ops
     q = torch.randn(2, 1, 16, 24, device="cuda").bfloat16()         # head_dim 12: not a multiple of 8
