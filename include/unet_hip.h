@@ -101,6 +101,20 @@ size_t unet_conv1d_wgrad_workspace_bytes(const UnetConvDesc* d);
 int unet_conv1d_wgrad(const UnetConvDesc* d, const void* x1, const void* x2, const void* dy,
                       float* dw, void* workspace, size_t ws_bytes, void* stream);
 
+/* Allocation-free variant of unet_conv1d_wgrad.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
+ * cannot allocate device memory around the call (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  Same arguments and result as unet_conv1d_wgrad (same kernels, same split count, so
+ * bit-identical dw), but the split-K slabs live in a device array built into the library instead of a
+ * caller-provided workspace: UNET_NOALLOC_SCRATCH_BYTES per GPU the library runs on, held until the process ends.
+ * A conv whose slabs (unet_conv1d_wgrad_workspace_bytes) exceed that size is rejected with an error.  The call
+ * allocates and frees nothing (no hipMalloc/hipFree, no allocating library routine).  All calls on one GPU share
+ * that GPU's array: calls that overlap on one GPU (two streams, two threads) race; calls ordered on one stream
+ * do not, and nothing needs clearing between them (every slab element read is written by the same call). */
+#define UNET_NOALLOC_SCRATCH_BYTES (32u << 20)
+size_t unet_conv1d_wgrad_noalloc_max_bytes(void);
+int unet_conv1d_wgrad_noalloc(const UnetConvDesc* d, const void* x1, const void* x2, const void* dy,
+                              float* dw, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Channels-last streaming kernels (HBM-bound).  "part" outputs are per-row-chunk partial
  * sums  [n][UNET_PARTS(rows)][c]  fp32; the caller adds them over the middle axis (tiny).

@@ -46,6 +46,8 @@ _SIGNATURES = {
     "unet_conv1d_last_variant": (C.c_int, []),
     "unet_conv1d_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "unet_conv1d_wgrad": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "unet_conv1d_wgrad_noalloc_max_bytes": (C.c_size_t, []),
+    "unet_conv1d_wgrad_noalloc": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     "unet_parts": (_i32, [_i32]),
     "unet_ncl_moments": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "unet_ncl_to_nlc": (C.c_int, [_i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

@@ -18,6 +18,7 @@
 //     ds_read_b128 lane group touches land on 16 distinct 16-B slots of the 256-B bank row.
 #include "common.h"
 #include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -1548,8 +1549,66 @@ extern "C" size_t unet_conv1d_wgrad_workspace_bytes(const UnetConvDesc* d) {
   return (size_t)s * d->n_taps * d->c_out * (d->c1 + d->c2) * sizeof(float);
 }
 
+namespace {
+int wgrad_impl(const UnetConvDesc* d, const void* x1, const void* x2, const void* dy, float* dw, void* workspace,
+               size_t ws_bytes, void* stream);
+}
+
 extern "C" int unet_conv1d_wgrad(const UnetConvDesc* d, const void* x1, const void* x2, const void* dy,
                                  float* dw, void* workspace, size_t ws_bytes, void* stream) {
+  return wgrad_impl(d, x1, x2, dy, dw, workspace, ws_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Allocation-free variant of unet_conv1d_wgrad (see include/unet_hip.h): the split-K slabs live in a
+// file-scope device array instead of a caller-provided workspace.  Every GPU the library runs on holds its own
+// copy of the array at its own address, resolved once per device with hipGetSymbolAddress; host code never
+// passes the array's name to a kernel, only that resolved pointer.
+// ---------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[UNET_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+void* g_scratch_ptr[MAX_DEVICES];          // per device: address of that device's copy of `scratch`
+std::mutex g_scratch_mutex;
+
+int scratch_for_current_device(void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  UNET_REQUIRE(e == hipSuccess, "conv_wgrad_noalloc: hipGetDevice failed: %s", hipGetErrorString(e));
+  UNET_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "conv_wgrad_noalloc: device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));   // the current device's copy
+    UNET_REQUIRE(e == hipSuccess && ptr, "conv_wgrad_noalloc: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+}  // namespace
+
+extern "C" size_t unet_conv1d_wgrad_noalloc_max_bytes(void) { return (size_t)UNET_NOALLOC_SCRATCH_BYTES; }
+
+extern "C" int unet_conv1d_wgrad_noalloc(const UnetConvDesc* d, const void* x1, const void* x2, const void* dy,
+                                         float* dw, void* stream) {
+  UNET_REQUIRE(d && x1 && dy && dw, "conv_wgrad_noalloc: null pointer");
+  const size_t need = unet_conv1d_wgrad_workspace_bytes(d);
+  UNET_REQUIRE(need > 0, "conv_wgrad_noalloc: bad descriptor");
+  UNET_REQUIRE(need <= (size_t)UNET_NOALLOC_SCRATCH_BYTES,
+               "conv_wgrad_noalloc: the split-K slabs of this conv need %zu bytes, the built-in scratch holds %zu; "
+               "use unet_conv1d_wgrad with a caller-provided workspace", need, (size_t)UNET_NOALLOC_SCRATCH_BYTES);
+  void* ptr = nullptr;
+  if (scratch_for_current_device(&ptr)) return -1;
+  // every slab element that slab_reduce_kernel reads is written by the weight-gradient kernel of the same call
+  // (blocks with an empty split store zeros), so nothing in the scratch has to be cleared between calls
+  return wgrad_impl(d, x1, x2, dy, dw, ptr, (size_t)UNET_NOALLOC_SCRATCH_BYTES, stream);
+}
+
+namespace {
+int wgrad_impl(const UnetConvDesc* d, const void* x1, const void* x2, const void* dy, float* dw, void* workspace,
+               size_t ws_bytes, void* stream) {
   UNET_REQUIRE(d && x1 && dy && dw, "conv_wgrad: null pointer");
   Phases ph;
   if (analyse(d, &ph)) return -1;
@@ -1625,3 +1684,4 @@ extern "C" int unet_conv1d_wgrad(const UnetConvDesc* d, const void* x1, const vo
   UNET_LAUNCH_CHECK("slab_reduce");
   return 0;
 }
+}  // namespace
