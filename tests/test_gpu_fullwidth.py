@@ -1,0 +1,316 @@
+"""Parity at the widths bench.py runs (GPU).
+
+1. Whole model at BASELINE.json's configurations B / B2 / C at FULL width (base=256; C: 128 channels in/out,
+   n_downsample=4, 446 M parameters) against records frozen from the reference itself
+   (oracle/make_golden_fullwidth.py -> tests/golden/fullwidth_*.npz: weights and inputs are regenerated from seeds,
+   the record holds the reference's loss, checksums and strided slices of outputs / activations / gradients).
+   fp32 bar: activations <= 2e-4, gradients <= 1e-3 relative L2 (north star: <= 1e-3); bf16 bars as in
+   tests/test_gpu_model.py (output <= 3e-2, loss <= 2e-2 abs, gradients <= 1e-1 under the linear loss).
+2. Every conv kernel at a config-B layer shape against fp32 torch convolutions on the GPU, with the dispatcher's
+   choice asserted (unet_conv1d_last_variant), forward / data-grad / weight-grad.
+3. N = 64 (the bench batch) through size-independent properties: eval-mode batch-split invariance, linearity of
+   the gradients in the batch (one 64-window step == eight accumulated 8-window steps: the split-K cost model and
+   the slab reduction at N = 64), and agreement of the 64 / 128 / 192-position tile variants on one layer.
+"""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.make_golden_fullwidth import CASES, block_names, build_case, strided, sums
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _record(name):
+    return np.load(os.path.join(GOLDEN, f"fullwidth_{name}.npz"), allow_pickle=False)
+
+
+def _slice_rel(t, z, key):
+    return rel(strided(t.float().cpu()), torch.from_numpy(z[key + "/slice"]))
+
+
+def _sum_err(t, z, key):
+    """|sum - ref sum| relative to the reference's sum of magnitudes (checksum over the WHOLE tensor)."""
+    mine, ref = sums(t.float().cpu()), z[key + "/sums"]
+    return abs(mine[0] - ref[0]) / max(ref[1], 1e-30), abs(mine[2] - ref[2]) / max(ref[2], 1e-30)
+
+
+def _model(name, dtype):
+    import unet_amd
+    kw, batch, T, (lo, hi) = CASES[name]
+    model, ob, tgt, ids = build_case(unet_amd.CondUNet1D, kw, batch, T)
+    model = model.cuda()
+    model.set_compute_dtype(dtype)
+    return model, ob.cuda(), tgt.cuda(), ids.cuda(), lo, hi
+
+
+def _train_forward(model, ob, ids):
+    acts, hooks = {}, []
+    for lname in block_names(model):
+        hooks.append(model.get_submodule(lname).register_forward_hook(
+            lambda _m, _i, o, lname=lname: acts.__setitem__(lname, o.detach())))
+    model.train()
+    pred, bott = model(ob, ids, return_bottleneck=True)
+    for h in hooks:
+        h.remove()
+    return pred, bott, acts
+
+
+@pytest.mark.parametrize("name", ["B", "B2", "C"])
+def test_fullwidth_fp32_matches_reference(name):
+    z = _record(name)
+    model, ob, tgt, ids, lo, hi = _model(name, torch.float32)
+    assert sum(p.numel() for p in model.parameters()) == ast.literal_eval(str(z["meta"]))["n_params"]
+    ob.requires_grad_(True)
+    pred, bott, acts = _train_forward(model, ob, ids)
+    loss = F.l1_loss(pred[..., lo:hi], tgt[..., lo:hi])
+    assert abs(loss.item() - float(z["loss"])) < 2e-5
+    assert _slice_rel(pred, z, "pred") < 2e-4 and max(_sum_err(pred, z, "pred")) < 2e-4
+    assert _slice_rel(bott, z, "bott") < 2e-4
+    for k, v in acts.items():
+        assert _slice_rel(v, z, f"act/{k}") < 2e-4, k
+        assert max(_sum_err(v, z, f"act/{k}")) < 2e-4, k
+    loss.backward()
+    assert _slice_rel(ob.grad, z, "grad_ob") < 1e-3
+    floor = 1e-6 * max(float(z[k][2]) for k in z.files if k.startswith("grad/") and k.endswith("/sums"))
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        if f"grad/{k}/sums" not in z.files:
+            continue
+        ref_norm = float(z[f"grad/{k}/sums"][2])
+        if ref_norm < floor:        # mathematically zero (conv bias in front of BatchNorm): noise on both sides
+            continue
+        assert p.grad is not None, k
+        e = max(_slice_rel(p.grad, z, f"grad/{k}"), _sum_err(p.grad, z, f"grad/{k}")[1])
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    assert worst[1] < 1e-3, worst
+    sd = model.state_dict()
+    for k in (k for k in z.files if k.startswith("bn/") and k.endswith("/slice")):
+        key = k[len("bn/"):-len("/slice")]
+        assert _slice_rel(sd[key], z, f"bn/{key}") < 1e-5, key
+    # eval mode on the updated buffers
+    model.eval()
+    with torch.no_grad():
+        pe = model(ob.detach(), ids)
+    assert _slice_rel(pe, z, "pred_eval") < 2e-4
+
+
+@pytest.mark.parametrize("name", ["B", "B2", "C"])
+def test_fullwidth_bf16_close_to_reference(name):
+    """bf16 kernels at full width (the dispatch paths the bench times: C = 512 / 1024 / 2048, 8-32 K-chunks,
+    192-wide tiles at L = 4096, the streaming single-tap kernel at C = 1024, stride-2 polyphase at C = 512)."""
+    z = _record(name)
+    model, ob, tgt, ids, lo, hi = _model(name, torch.bfloat16)
+    pred, bott, acts = _train_forward(model, ob, ids)
+    assert pred.dtype == torch.float32
+    assert _slice_rel(pred, z, "pred") < 3e-2
+    loss = F.l1_loss(pred[..., lo:hi], tgt[..., lo:hi])
+    assert abs(loss.item() - float(z["loss"])) < 2e-2
+    for k, v in acts.items():
+        assert _slice_rel(v, z, f"act/{k}") < 3e-2, k
+    # gradients under the linear loss <pred, G> of the record (G regenerated from its seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.momentum = 0.0
+    G = torch.randn(pred.shape, generator=torch.Generator().manual_seed(99)) / pred.numel()
+    model.zero_grad(set_to_none=True)
+    pred2 = model(ob, ids)
+    (pred2 * G.cuda()).sum().backward()
+    norms = {k[len("lingrad/"):-len("/sums")]: float(z[k][2]) for k in z.files
+             if k.startswith("lingrad/") and k.endswith("/sums")}
+    floor = 1e-5 * max(norms.values())
+    bad = []
+    for k, p in model.named_parameters():
+        if k not in norms or norms[k] < floor:
+            continue
+        e = _slice_rel(p.grad, z, f"lingrad/{k}")
+        tol = 3e-1 if p.numel() <= 4 else 1e-1       # scale_weights: differences of large sums (tests/test_gpu_model.py)
+        if e > tol:
+            bad.append((k, e))
+    assert not bad, bad
+    model.eval()
+    with torch.no_grad():
+        pe = model(ob, ids)
+    assert _slice_rel(pe, z, "pred_eval") < 3e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# conv kernels at config-B layer shapes, dispatcher's choice asserted
+# ---------------------------------------------------------------------------------------------------------------
+FWD_TILED, FWD_STREAM, WGRAD_PAIRED = 2, 3, 12
+LAYER_CASES = [
+    # (tag, cin, cout, L, k, stride, dilation, expected forward variant)
+    ("mid_k3_c1024", 1024, 1024, 1024, 3, 1, 1, FWD_TILED),
+    ("enc_k3_s2_c512", 512, 1024, 2048, 3, 2, 1, FWD_TILED),
+    ("film_k1_c1024", 1024, 1024, 1024, 1, 1, 1, FWD_STREAM),
+    ("film_k1_c256", 256, 256, 4096, 1, 1, 1, FWD_STREAM),
+    ("branch_k7_d32_c512", 512, 512, 2048, 7, 1, 32, FWD_TILED),
+    ("outc_k3", 256, 32, 4096, 3, 1, 1, FWD_TILED),
+    ("inc_k7_d16_cin32", 32, 256, 4096, 7, 1, 16, FWD_TILED),
+]
+
+
+@pytest.mark.parametrize("case", LAYER_CASES, ids=[c[0] for c in LAYER_CASES])
+def test_conv_kernels_at_config_b_layer_shapes(case):
+    from unet_amd import _lib, ops
+    lib = _lib.load()
+    _, cin, cout, L, k, stride, dil, want = case
+    n = 8
+    g = torch.Generator().manual_seed(L + cin)
+    x = torch.randn(n, cin, L, generator=g).bfloat16().cuda()
+    w = (torch.randn(cout, cin, k, generator=g) / (cin * k) ** 0.5).bfloat16().float().cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    pad = (k - 1) * dil // 2
+    xr, wr, br = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv1d(xr, wr, br, stride=stride, padding=pad, dilation=dil)
+    dy = torch.randn(yr.shape, generator=g).bfloat16().cuda()
+    yr.backward(dy.float())
+    geom = ops.geom_conv(k, stride, dil)
+    xd = x.permute(0, 2, 1).contiguous().requires_grad_(True)
+    wd, bd = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = ops.conv(xd, wd.permute(2, 0, 1), bd, geom, yr.shape[-1])
+    assert int(lib.unet_conv1d_last_variant()) == want
+    dyd = dy.permute(0, 2, 1).contiguous()
+    y.backward(dyd)
+    ops.conv_wgrad_raw(geom, xd.detach(), None, dyd, cout)          # same call on this thread: which kernel ran
+    assert int(lib.unet_conv1d_last_variant()) == WGRAD_PAIRED
+    assert rel(y.permute(0, 2, 1), yr) < 1e-2
+    assert rel(xd.grad.permute(0, 2, 1), xr.grad) < 1e-2
+    assert rel(wd.grad, wr.grad) < 1e-2
+    assert rel(bd.grad, br.grad) < 1e-2
+
+
+@pytest.mark.parametrize("shape", [(1024, 512, 1024), (512, 256, 2048)])
+def test_conv_transpose_at_config_b_layer_shapes(shape):
+    from unet_amd import _lib, ops
+    lib = _lib.load()
+    cin, cout, L = shape
+    n = 8
+    g = torch.Generator().manual_seed(L)
+    x = torch.randn(n, cin, L, generator=g).bfloat16().cuda()
+    w = (torch.randn(cin, cout, 4, generator=g) / (cin * 2) ** 0.5).bfloat16().float().cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    res = torch.randn(n, cout, 2 * L, generator=g).bfloat16().cuda()
+    xr, wr, br = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv_transpose1d(xr, wr, br, stride=2, padding=1) + res.float()
+    dy = torch.randn(yr.shape, generator=g).bfloat16().cuda()
+    yr.backward(dy.float())
+    geom, kidx = ops.geom_convt_k4s2p1()
+    xd = x.permute(0, 2, 1).contiguous().requires_grad_(True)
+    wd, bd = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = ops.conv(xd, wd.permute(2, 1, 0)[list(kidx)], bd, geom, 2 * L, res=res.permute(0, 2, 1).contiguous())
+    assert int(lib.unet_conv1d_last_variant()) == FWD_TILED
+    y.backward(dy.permute(0, 2, 1).contiguous())
+    assert rel(y.permute(0, 2, 1), yr) < 1e-2
+    assert rel(xd.grad.permute(0, 2, 1), xr.grad) < 1e-2
+    assert rel(wd.grad, wr.grad) < 1e-2
+    assert rel(bd.grad, br.grad) < 1e-2
+
+
+@pytest.mark.parametrize("shape", [(512, 1024, 2048, 2), (512, 512, 2048, 1), (256, 256, 4096, 1)])
+def test_merged_dilated_conv_at_config_b_layer_shapes(shape):
+    """enc1 (stride-2 polyphase, C 512 -> 1024), dec0 (192-position tiles) and dec1 of config B: the 23-tap merged
+    conv with all parameter gradients against four fp32 F.conv1d branches on the GPU."""
+    import unet_amd
+    from unet_amd import _lib
+    cin, cout, L, stride = shape
+    n = 8
+    torch.manual_seed(cin + stride)
+    blk = unet_amd.MultiScaleDilatedConv1d(cin, cout, 7, stride, (1, 4, 16, 32))
+    with torch.no_grad():
+        blk.scale_weights.copy_(torch.tensor([0.1, 0.5, -0.3, 0.2]))
+        for p in blk.parameters():
+            if p.dim() == 3:
+                p.copy_(p.bfloat16().float())
+    blk = blk.cuda()
+    x = torch.randn(n, cin, L).bfloat16().cuda()
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in blk.named_parameters()}
+    xr = x.float().requires_grad_(True)
+    wsm = torch.softmax(params["scale_weights"], 0)
+    yr = 0
+    for i, d in enumerate((1, 4, 16, 32)):
+        yr = yr + wsm[i] * F.conv1d(xr, params[f"branches.{i}.conv.weight"], params[f"branches.{i}.conv.bias"],
+                                    stride=stride, padding=3 * d, dilation=d)
+    dy = torch.randn(yr.shape, device="cuda").bfloat16()
+    yr.backward(dy.float())
+    xd = x.permute(0, 2, 1).contiguous().requires_grad_(True)
+    y = blk.forward_nlc(xd)
+    assert int(_lib.load().unet_conv1d_last_variant()) == FWD_TILED
+    y.backward(dy.permute(0, 2, 1).contiguous())
+    assert rel(y.permute(0, 2, 1), yr) < 1.5e-2
+    assert rel(xd.grad.permute(0, 2, 1), xr.grad) < 1.5e-2
+    for k, p in blk.named_parameters():
+        # scale_weights: 4 numbers, each the difference of sums over 10^7 products (see tests/test_gpu_model.py)
+        assert rel(p.grad, params[k].grad) < (5e-2 if p.numel() <= 4 else 1.5e-2), k
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# N = 64 (the bench batch): size-independent properties
+# ---------------------------------------------------------------------------------------------------------------
+def test_n64_eval_batch_split_invariance_and_gradient_linearity():
+    z = _record("B")
+    model, ob, tgt, ids, lo, hi = _model("B", torch.bfloat16)
+    model.eval()                               # running statistics: windows are independent of each other
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(64, 32, 4096, generator=g).cuda()
+    x[:2] = ob
+    id64 = torch.randint(0, 7, (64,), generator=g).cuda()
+    id64[:2] = ids
+    with torch.no_grad():
+        out64 = model(x, id64)
+        out2 = model(x[:2].contiguous(), id64[:2])
+        out8 = model(x[8:16].contiguous(), id64[8:16])
+    # the same windows inside a 64-window batch and alone.  Not bit-exact: the [N, 128] -> [N, C] Linear layers of
+    # SE / FiLM run on library GEMMs whose algorithm (summation order) depends on N, and an fp32 ulp there flips bf16
+    # roundings downstream; the bar is 1/15 of the bf16 output bar
+    assert rel(out64[:2], out2) < 2e-3
+    assert rel(out64[8:16], out8) < 2e-3
+    assert _slice_rel(out2, z, "pred_eval") < 3e-2   # and the two golden windows still match the reference
+    # gradient linearity in the batch: one 64-window backward == eight accumulated 8-window backwards
+    G = torch.randn(out64.shape, generator=torch.Generator().manual_seed(6)).cuda() / out64[0].numel()
+    model.zero_grad(set_to_none=True)
+    (model(x, id64) * G).sum().backward()
+    g64 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    for i in range(0, 64, 8):
+        (model(x[i:i + 8].contiguous(), id64[i:i + 8]) * G[i:i + 8]).sum().backward()
+    floor = 1e-5 * max(v.norm().item() for v in g64.values())
+    bad = []
+    for k, p in model.named_parameters():
+        if k not in g64 or g64[k].norm().item() < floor:
+            continue
+        e = rel(p.grad, g64[k])
+        if e > (5e-2 if p.numel() <= 4 else 1e-2):   # same bf16 products, different fp32 summation order
+            bad.append((k, e))
+    assert not bad, bad
+
+
+def test_tile_width_variants_agree():
+    """The 192-, 128- and 64-position tiles of conv_fwd2 on one config-B layer (dec0's merged conv, N = 64)."""
+    import unet_amd
+    torch.manual_seed(3)
+    blk = unet_amd.MultiScaleDilatedConv1d(512, 512, 7, 1, (1, 4, 16, 32)).cuda()
+    x = torch.randn(64, 2048, 512, device="cuda").bfloat16()
+    outs = {}
+    try:
+        for bn in ("", "128", "64"):
+            if bn:
+                os.environ["UNET_CONV_BN"] = bn
+            else:
+                os.environ.pop("UNET_CONV_BN", None)
+            with torch.no_grad():
+                outs[bn] = blk.forward_nlc(x).float()
+    finally:
+        os.environ.pop("UNET_CONV_BN", None)
+    assert rel(outs["128"], outs[""]) < 1e-6
+    assert rel(outs["64"], outs[""]) < 1e-6
