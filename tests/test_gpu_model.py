@@ -51,20 +51,19 @@ def test_fp32_train_step_matches_reference(name):
     model = _build(g)
     model.train()
     acts = {}
-    hooks = []
-    for lname in model.get_layer_names():
-        mod = model.get_submodule(lname)
-        hooks.append(mod.register_forward_hook(lambda _m, _i, o, lname=lname: acts.__setitem__(lname, o.detach())))
+    hooks = model.register_activation_hooks(lambda lname, o: acts.__setitem__(lname, o.detach()))
     ob = g.t("ob").cuda().requires_grad_(True)
     pred, bott = model(ob, return_bottleneck=True, **_kw(g))
     for h in hooks:
         h.remove()
+    assert list(acts) == model.get_layer_names()
     assert pred.shape == g.t("pred").shape and pred.dtype == torch.float32
     assert rel(pred, g.t("pred")) < 1e-4
     assert rel(bott, g.t("bottleneck")) < 1e-4
     for k, v in g.group("act/").items():
-        if k == "outc":
-            continue  # the reference's hook sees delta; ours fuses the residual into outc's epilogue
+        # fixture keys are module paths (encoders.0); the hook names are the reference's (encoder_0); the hook on
+        # outc sees delta, before the residual, as the reference's does
+        k = k.replace("encoders.", "encoder_").replace("decoders.", "decoder_")
         assert acts[k].shape == v.shape, k
         assert rel(acts[k], v) < 1e-4, k
     loss = F.l1_loss(pred[..., g.lo:g.hi], g.t("target").cuda()[..., g.lo:g.hi])

@@ -113,3 +113,30 @@ def test_same_seed_same_initial_weights_as_reference():
                 ref = z[f"{tag}/{k}"]
                 got = np.array([v.double().sum().item(), v.double().abs().sum().item()])
                 assert np.allclose(got, ref, rtol=1e-12, atol=1e-12), (tag, k)
+
+
+@pytest.mark.parametrize("name", ["A_std_attn_add_bn", "B_modern_add_bn_gelu", "std_crossfreq_v2"])
+def test_introspection_names_and_norms_match_reference_on_cpu(name):
+    """Row a16 without a GPU: the parameter-only part of the reference's introspection surface (models.py:3381-3627)
+    against outputs of the reference's own methods (oracle/make_golden_introspect.py)."""
+    import json
+    import numpy as np
+    import unet_amd
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(gdir, f"introspect_{name}.npz"), allow_pickle=False)
+    with open(os.path.join(gdir, f"introspect_{name}.json")) as f:
+        info = json.load(f)
+    model = unet_amd.CondUNet1D(**info["cfg"])
+    model.load_state_dict({k[3:]: torch.from_numpy(np.array(z[k])) for k in z.files if k.startswith("sd/")}, strict=True)
+    assert model.get_layer_names() == info["layer_names"]
+    assert model.get_layer_parameter_counts() == info["param_counts"]
+    assert model.get_architecture_summary() == info["architecture_summary"]
+    assert [type(m).__name__ for m in model.get_encoder_layers()] == info["encoder_layers"]
+    assert [type(m).__name__ for m in model.get_decoder_layers()] == info["decoder_layers"]
+    att = model.get_attention_module()
+    assert (None if att is None else type(att).__name__) == info["attention_module"]
+    wn = model.get_weight_norms()
+    assert sorted(wn) == sorted(info["weight_norms"])
+    for k, v in info["weight_norms"].items():
+        assert abs(wn[k] - v) <= 1e-6 * abs(v), k
+    assert model.get_gradient_norms() == {}          # no backward yet

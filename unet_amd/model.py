@@ -820,22 +820,122 @@ class CondUNet1D(nn.Module):
                 _ = self(x.to(device))
         self.eval()
 
+    # -- introspection / analysis surface (models.py:3381-3703) -------------------------------------
     def get_layer_names(self) -> List[str]:
-        names = ["inc"] + [f"encoders.{i}" for i in range(self.n_downsample)] + ["mid"]
-        names += [f"decoders.{i}" for i in range(self.n_downsample)] + ["outc"]
-        return names
+        """models.py:3381-3392 (names used by the recorder, not module paths)."""
+        return (["inc"] + [f"encoder_{i}" for i in range(self.n_downsample)] + ["mid"] +
+                [f"decoder_{i}" for i in range(self.n_downsample)] + ["outc"])
+
+    def _named_blocks(self, mid_name: str = "mid"):
+        """(reference layer name, module) in network order."""
+        return ([("inc", self.inc)] + [(f"encoder_{i}", m) for i, m in enumerate(self.encoders)] +
+                [(mid_name, self.mid)] + [(f"decoder_{i}", m) for i, m in enumerate(self.decoders)] +
+                [("outc", self.outc)])
+
+    def register_activation_hooks(self, callback) -> List:
+        """models.py:3394-3437: callback(layer_name, activation) on every forward; activations are the
+        reference's ``[B, C, L]`` tensors (views of the channels-last storage), ``outc`` sees ``delta`` before the
+        residual.  Returns the hook handles."""
+        return [mod.register_forward_hook(lambda m, i, o, n=name: callback(n, o)) for name, mod in self._named_blocks()]
+
+    def get_encoder_layers(self) -> List[nn.Module]:
+        return [self.inc] + list(self.encoders)
+
+    def get_decoder_layers(self) -> List[nn.Module]:
+        return list(self.decoders) + [self.outc]
+
+    def get_attention_module(self) -> Optional[nn.Module]:
+        """The cross-frequency attention module of the bottleneck, if any (models.py:3455-3464)."""
+        for module in self.mid.modules():
+            if hasattr(module, "coupling_weights"):
+                return module
+        return None
+
+    def _get_first_conv_weight(self, module) -> Optional[Tensor]:
+        """The tensor the reference's recorder calls a layer's "first conv weight" (models.py:3470-3495).  The
+        search order is part of the contract: own ``weight``; then attributes conv / conv1 / conv_in; then the
+        items of a Sequential / ModuleList; then direct Conv1d / Conv2d / Linear children.  (For a modern block
+        that is the BatchNorm weight: the multi-scale conv has no ``weight`` of its own; for an up block with
+        equal skip / output channels it is None.)"""
+        if module is None:
+            return None
+        w = getattr(module, "weight", None)
+        if w is not None:
+            return w
+        for attr in ("conv", "conv1", "conv_in"):
+            if hasattr(module, attr):
+                w = self._get_first_conv_weight(getattr(module, attr))
+                if w is not None:
+                    return w
+        if isinstance(module, (nn.Sequential, nn.ModuleList)):
+            for child in module:
+                w = self._get_first_conv_weight(child)
+                if w is not None:
+                    return w
+        for child in module.children():
+            if getattr(child, "weight", None) is not None and isinstance(child, (nn.Conv1d, nn.Conv2d, nn.Linear)):
+                return child.weight
+        return None
+
+    def _recorder_weights(self):
+        """(key, tensor) pairs behind get_gradient_norms / get_weight_norms: inc, encoder_i, mid_j (one per item of
+        the bottleneck Sequential that has a weight), decoder_i, outc."""
+        out = [("inc", self._get_first_conv_weight(self.inc))]
+        out += [(f"encoder_{i}", self._get_first_conv_weight(m)) for i, m in enumerate(self.encoders)]
+        out += [(f"mid_{j}", self._get_first_conv_weight(m)) for j, m in enumerate(self.mid)]
+        out += [(f"decoder_{i}", self._get_first_conv_weight(m)) for i, m in enumerate(self.decoders)]
+        out += [("outc", self._get_first_conv_weight(self.outc))]
+        return [(k, w) for k, w in out if w is not None]
 
     def get_gradient_norms(self) -> dict:
-        """Per-block norm of the first conv weight's gradient (models.py:3497)."""
-        out = {}
-        blocks = [("inc", self.inc)] + [(f"encoders.{i}", m) for i, m in enumerate(self.encoders)] + \
-                 [(f"decoders.{i}", m) for i, m in enumerate(self.decoders)]
-        for name, blk in blocks:
-            for p in blk.parameters():
-                if p.dim() == 3 and p.grad is not None:
-                    out[name] = float(p.grad.norm())
-                    break
-        return out
+        """models.py:3497-3535 (read by train.py:1549-1551 after backward)."""
+        return {k: w.grad.norm().item() for k, w in self._recorder_weights() if w.grad is not None}
+
+    def get_weight_norms(self) -> dict:
+        """models.py:3537-3573."""
+        return {k: w.norm().item() for k, w in self._recorder_weights()}
+
+    def get_layer_parameter_counts(self) -> dict:
+        """models.py:3575-3605."""
+        counts = {name: sum(p.numel() for p in mod.parameters()) for name, mod in self._named_blocks()}
+        if self.embed is not None:
+            counts["embed"] = sum(p.numel() for p in self.embed.parameters())
+        return counts
+
+    def get_architecture_summary(self) -> dict:
+        """models.py:3607-3627."""
+        return {
+            "n_downsample": self.n_downsample, "in_channels": self.in_channels, "out_channels": self.out_channels,
+            "base_channels": self.base, "cond_mode": self.cond_mode, "skip_type": self.skip_type,
+            "use_attention": self.use_attention, "attention_type": self.attention_type,
+            "use_residual": self.use_residual,
+            "total_params": sum(p.numel() for p in self.parameters()),
+            "trainable_params": sum(p.numel() for p in self.parameters() if p.requires_grad),
+            "layer_param_counts": self.get_layer_parameter_counts(),
+            "layer_names": self.get_layer_names(),
+        }
+
+    @torch.no_grad()
+    def extract_all_activations(self, x: Tensor, odor_ids: Optional[Tensor] = None, cond_emb: Optional[Tensor] = None,
+                                session_ids: Optional[Tensor] = None) -> dict:
+        """models.py:3629-3672: one forward pass, every block's output (the bottleneck under the key 'bottleneck')."""
+        activations = {}
+        hooks = [mod.register_forward_hook(lambda m, i, o, n=name: activations.__setitem__(n, o.detach().clone()))
+                 for name, mod in self._named_blocks(mid_name="bottleneck")]
+        try:
+            self.forward(x, odor_ids=odor_ids, cond_emb=cond_emb, session_ids=session_ids)
+        finally:
+            for h in hooks:
+                h.remove()
+        return activations
+
+    @torch.no_grad()
+    def get_bottleneck_features(self, x: Tensor, odor_ids: Optional[Tensor] = None, cond_emb: Optional[Tensor] = None,
+                                session_ids: Optional[Tensor] = None, pool: bool = True) -> Tensor:
+        """models.py:3674-3703: pooled [B, C] or temporal [B, C, T'] bottleneck features."""
+        _, bottleneck = self.forward(x, odor_ids=odor_ids, cond_emb=cond_emb, session_ids=session_ids,
+                                     return_bottleneck=pool, return_bottleneck_temporal=not pool)
+        return bottleneck
 
     # -- forward --------------------------------------------------------------------------------
     def forward(
@@ -893,7 +993,13 @@ class CondUNet1D(nn.Module):
             res = x0
         else:
             res = ops.conv(x0, self.residual_conv.weight.permute(2, 0, 1), self.residual_conv.bias, ops.geom_conv(1), l)
-        out_nlc = ops.conv(x, self.outc.weight.permute(2, 0, 1), self.outc.bias, ops.geom_conv(3), l, res=res)
+        if self.outc._forward_hooks or self.outc._forward_pre_hooks:
+            # a hook on outc must see delta before the residual (models.py:3359-3366): unfused
+            def outc_delta(_blk, xin):
+                return ops.conv(xin, self.outc.weight.permute(2, 0, 1), self.outc.bias, ops.geom_conv(3), l)
+            out_nlc = _HookedCall.run(self.outc, outc_delta, x) + res
+        else:
+            out_nlc = ops.conv(x, self.outc.weight.permute(2, 0, 1), self.outc.bias, ops.geom_conv(3), l, res=res)
         out = ops.ToNCLFn.apply(out_nlc, io_dtype)
         if self.use_adaptive_scaling:
             out = self.adaptive_scaler(out, raw_input)
