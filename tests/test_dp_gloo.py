@@ -148,12 +148,13 @@ def _coalesce_worker(rank, world, port, q):
     from unet_amd.dp import coalesced_grad_mean
     torch.manual_seed(0)
     m = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.LayerNorm(7), torch.nn.Linear(7, 2))
-    extra = torch.nn.Parameter(torch.ones(3))               # no gradient: skipped
+    extra = torch.nn.Parameter(torch.ones(3))               # no gradient on any rank: sent as zeros, comes back as zeros
     torch.manual_seed(50 + rank)
     m(torch.randn(6, 5)).square().sum().backward()
     local = [p.grad.clone() for p in m.parameters()]
     coalesced_grad_mean(list(m.parameters()) + [extra])
-    q.put((rank, [g.numpy().copy() for g in local], [p.grad.numpy().copy() for p in m.parameters()], extra.grad is None))
+    q.put((rank, [g.numpy().copy() for g in local], [p.grad.numpy().copy() for p in m.parameters()],
+           extra.grad is not None and float(extra.grad.abs().max()) == 0.0))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -178,3 +179,81 @@ def test_coalesced_grad_mean_two_ranks():
         assert torch.allclose(torch.from_numpy(res[0][1][i]), torch.from_numpy(want), atol=1e-7)
         assert (res[0][1][i] == res[1][1][i]).all()
     assert res[0][2] and res[1][2]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fold-parallel LOSO with a real Trainer per job: jobs must not join the WORLD collectives (dp.NO_GROUP)
+# ---------------------------------------------------------------------------------------------------------------
+class _TinyModel(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+
+    def forward(self, x, odor_ids=None):
+        return self.net(x)
+
+
+def _fold_job(job, ckpt_dir=None):
+    """One LOSO job on a tiny torch model: Trainer steps, early-stop bookkeeping, a checkpoint.  Deterministic in
+    the job's seed, so a serial run and a fold-parallel run must produce the same weights."""
+    import torch.nn.functional as F
+    from unet_amd.checkpoint import EarlyStopping, save_checkpoint
+    from unet_amd.dp import NO_GROUP
+    from unet_amd.trainer import Trainer
+    torch.manual_seed(job.run_seed)
+    model = _TinyModel()
+    tr = Trainer(model, lr=1e-2, compute_dtype=None, process_group=NO_GROUP, loss_fn=F.l1_loss,
+                 normalize_target=lambda t: t)
+    assert tr.world == 1 and tr.reducer.world == 1
+    stopper = EarlyStopping(2, NO_GROUP)
+    g = torch.Generator().manual_seed(1000 + job.run_seed)
+    losses = []
+    for epoch in range(1, 4 + job.fold_idx):          # different folds run different numbers of steps
+        x, y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+        loss = float(tr.step(x, y))
+        losses.append(loss)
+        val = stopper.sync_val_loss(loss, x.device)
+        if stopper.update(val, epoch) and ckpt_dir is not None:
+            save_checkpoint(model, tr.opt, epoch, os.path.join(ckpt_dir, f"f{job.fold_idx}s{job.seed_idx}.pt"),
+                            process_group=NO_GROUP)
+        if stopper.should_stop(x.device):
+            break
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    return {"val_r2": float(flat.sum()), "val_corr": float(flat.abs().sum()), "val_loss": losses[-1]}
+
+
+def _loso_trainer_worker(rank, world, port, q, ckpt_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unet_amd.trainer import run_loso
+    out = run_loso(["a", "b", "c"], lambda job: _fold_job(job, ckpt_dir), seed=7, n_seeds=1)   # 3 jobs on 2 ranks
+    q.put((rank, out["per_fold"], out["summary"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fold_parallel_loso_with_real_trainers_equals_serial(tmp_path):
+    """Uneven job counts (3 jobs, 2 ranks), every job building its own Trainer / EarlyStopping / checkpoint with
+    dp.NO_GROUP: no job may broadcast weights, average gradients or wait for the other rank (it would deadlock or
+    mix folds).  Each rank's results equal the serial run's, and every job wrote its own checkpoint."""
+    from unet_amd.folds import loso_jobs
+    from unet_amd.trainer import run_loso
+    serial = run_loso(["a", "b", "c"], _fold_job, seed=7, n_seeds=1)      # no process group here: the reference order
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_loso_trainer_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, per_fold, summary = q.get(timeout=180)
+        res[rank] = (per_fold, summary)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        assert res[rank][0] == serial["per_fold"], rank
+        assert res[rank][1] == serial["summary"], rank
+    jobs = loso_jobs(["a", "b", "c"], 7, 1, None)
+    assert sorted(os.listdir(tmp_path)) == sorted(f"f{j.fold_idx}s{j.seed_idx}.pt" for j in jobs)

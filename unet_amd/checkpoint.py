@@ -26,7 +26,8 @@ import torch.distributed as dist
 
 
 def _is_primary(process_group=None) -> bool:
-    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank(process_group) == 0
+    from .dp import group_rank
+    return group_rank(process_group) == 0        # NO_GROUP (a fold job of run_loso): every rank is its own primary
 
 
 def _unwrap(model):
@@ -110,7 +111,8 @@ class EarlyStopping:
 
     def sync_val_loss(self, val_loss: float, device) -> float:
         """train.py:2516-2520: mean over ranks."""
-        if dist.is_available() and dist.is_initialized():
+        from .dp import group_active
+        if group_active(self.pg):
             t = torch.tensor(float(val_loss), device=device)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)         # gloo has no AVG; SUM / world is the same value
             val_loss = float(t.item()) / dist.get_world_size(self.pg)
@@ -129,8 +131,9 @@ class EarlyStopping:
 
     def should_stop(self, device=None) -> bool:
         """train.py:2744-2750: rank 0's decision, broadcast."""
+        from .dp import group_active
         stop = self.patience_counter >= self.patience
-        if dist.is_available() and dist.is_initialized():
+        if group_active(self.pg):
             t = torch.tensor([1 if stop else 0], dtype=torch.int32, device=device)
             dist.broadcast(t, src=0, group=self.pg)
             stop = int(t.item()) == 1

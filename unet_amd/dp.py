@@ -27,20 +27,50 @@ import torch
 import torch.distributed as dist
 
 
+NO_GROUP = False
+"""Pass as ``process_group`` to say "this job is NOT data-parallel", even though ``torch.distributed`` is
+initialised: fold-parallel LOSO runs a different (fold, seed) job on every rank (``trainer.run_loso``), and such a
+job must not broadcast weights, average gradients or share early-stop decisions with the other ranks."""
+
+
+def group_active(process_group=None) -> bool:
+    return process_group is not NO_GROUP and dist.is_available() and dist.is_initialized()
+
+
+def group_size(process_group=None) -> int:
+    return dist.get_world_size(process_group) if group_active(process_group) else 1
+
+
+def group_rank(process_group=None) -> int:
+    return dist.get_rank(process_group) if group_active(process_group) else 0
+
+
 class BucketedGradAllReduce:
-    def __init__(self, params, bucket_bytes: int = 64 << 20, process_group=None, average: bool = True):
+    def __init__(self, params, bucket_bytes: int = 64 << 20, process_group=None, average: bool = True,
+                 tail_bytes: int = 4 << 20):
+        """``tail_bytes``: the parameters registered first (embedding, ``inc``) produce their gradients last, and the
+        bucket that holds them is launched when backward has nothing left to overlap it with; they get a bucket of
+        their own of at most this size, so the exposed message is a few MiB instead of a full bucket."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.pg = process_group
         self.average = average
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.world = group_size(process_group)
         self.buckets: List[torch.Tensor] = []
         self._groups: List[List[torch.nn.Parameter]] = []
         self._views: List[List[torch.Tensor]] = []
         self._bucket_of = {}
         self._handles = []
         self._hooks = []
+        n_tail, tail_elems = 0, 0
+        for p in self.params:
+            if (tail_elems + p.numel()) * 4 > tail_bytes:
+                break
+            n_tail += 1
+            tail_elems += p.numel()
+        if n_tail == len(self.params):
+            n_tail = 0                          # everything fits one small bucket: no separate tail
         cur, cur_elems = [], 0
-        for p in reversed(self.params):
+        for p in reversed(self.params[n_tail:]):
             if p.dtype != torch.float32:
                 raise TypeError("gradient buckets are fp32 (master weights are fp32, as in the reference)")
             if cur and (cur_elems + p.numel()) * 4 > bucket_bytes:
@@ -50,6 +80,8 @@ class BucketedGradAllReduce:
             cur_elems += p.numel()
         if cur:
             self._groups.append(cur)
+        if n_tail:
+            self._groups.append(list(reversed(self.params[:n_tail])))
         for b, group in enumerate(self._groups):
             flat = torch.zeros(sum(p.numel() for p in group), dtype=torch.float32, device=group[0].device)
             views, off = [], 0
@@ -125,7 +157,7 @@ def _has_avg(process_group=None) -> bool:
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=None):
     """What DDP's constructor does once: make every rank start from rank `src`'s parameters and
     buffers (train.py seeds ranks differently, `seed + rank`, train.py:763-764)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+    if group_size(process_group) == 1:
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
@@ -136,21 +168,25 @@ def coalesced_grad_mean(params, process_group=None):
     """Mean of the gradients of a SMALL module across ranks in ONE message -- the reference's
     ``sync_gradients_manual`` (train.py:738-758) issues one all-reduce per parameter (28 tiny collectives for the
     conditioning encoder); xGMI collectives are latency-bound at that size, so the gradients are flattened into
-    one fp32 buffer, reduced once and copied back.  No-op without an initialised process group."""
-    if not (dist.is_available() and dist.is_initialized()):
-        return
-    world = dist.get_world_size(process_group)
+    one fp32 buffer, reduced once and copied back.  No-op without an initialised process group or with ``NO_GROUP``."""
+    world = group_size(process_group)
     if world == 1:
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    params = [p for p in params if p.requires_grad]
+    if not params:
         return
-    flat = torch.cat([g.detach().reshape(-1).float() for g in grads])
+    # every rank sends the same layout: a parameter without a gradient on this rank contributes zeros (and gets the
+    # mean of the others), so ranks whose gradients differ in presence cannot mismatch message sizes
+    flat = torch.cat([(p.grad.detach().reshape(-1).float() if p.grad is not None
+                       else torch.zeros(p.numel(), dtype=torch.float32, device=p.device)) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
     flat.div_(world)
     off = 0
     with torch.no_grad():
-        for g in grads:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
+        for p in params:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = flat[off:off + n].view_as(p).to(p.dtype).clone()
+            else:
+                p.grad.copy_(flat[off:off + n].view_as(p))
             off += n

@@ -20,7 +20,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
-from .dp import _has_avg
+from .dp import _has_avg, group_size
 
 
 class GraphedTrainStep:
@@ -44,7 +44,7 @@ class GraphedTrainStep:
         self.static_in = [t.clone() for t in inputs]
         self.static_tg = [t.clone() for t in targets]
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.world = group_size(process_group)
 
         def fwd_bwd():
             out = (forward or model)(*self.static_in)
@@ -139,11 +139,15 @@ class GraphedTrainStep:
 
     # -- per step ---------------------------------------------------------------------------------
     def __call__(self, inputs: Optional[Sequence[torch.Tensor]] = None, targets: Optional[Sequence[torch.Tensor]] = None):
-        if inputs is not None:
-            for s, t in zip(self.static_in, inputs):
-                s.copy_(t, non_blocking=True)
-        if targets is not None:
-            for s, t in zip(self.static_tg, targets):
+        for static, new in ((self.static_in, inputs), (self.static_tg, targets)):
+            if new is None:
+                continue
+            if len(new) != len(static):
+                raise ValueError(f"captured step takes {len(static)} tensors here, got {len(new)}")
+            for s, t in zip(static, new):
+                if t.shape != s.shape:       # copy_ would broadcast a batch of 1 into every row without a word
+                    raise ValueError(f"captured step was recorded for batches of shape {tuple(s.shape)}, got "
+                                     f"{tuple(t.shape)}: run other shapes (a last partial batch) through an eager step")
                 s.copy_(t, non_blocking=True)
         self.graph.replay()
         if self.graph_update is not None:

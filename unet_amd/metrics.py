@@ -152,7 +152,8 @@ class PooledStats:
         self.r2_list.append(1.0 - (tot[6] / n) / var)
 
     def all_reduce(self, group=None):
-        if dist.is_available() and dist.is_initialized():
+        from .dp import group_active
+        if group_active(group):                                             # dp.NO_GROUP: a fold job, nothing to pool
             dist.all_reduce(self.sums, op=dist.ReduceOp.SUM, group=group)   # train.py:1087
 
     def finalize(self) -> Dict[str, float]:

@@ -9,9 +9,20 @@ metrics of ``evaluate`` (train.py:776-1291) for the model in scope:
     loss.backward()  (bucketed RCCL all-reduce overlapped, replaces DDP)   train.py:1546, 2161-2181
     clip_grad_norm_(5.0); AdamW.step(); zero_grad(set_to_none)              train.py:1553-1560
 
-One process per GPU (``torchrun``); ``Trainer`` picks up ``torch.distributed`` if it is initialised.
+One process per GPU (``torchrun``); ``Trainer`` picks up ``torch.distributed`` if it is initialised, unless it is
+built with ``process_group=dp.NO_GROUP`` -- the mode for jobs that share the process group but not the model
+(fold-parallel LOSO, ``run_loso``): no weight broadcast, no gradient / metric / early-stop collectives, every rank
+writes its own checkpoint.
 The NaN/Inf abort of train.py:1543 is kept but checked on the device and read every ``nan_check_every``
-steps instead of syncing the host every step.
+steps instead of syncing the host every step: when it raises, up to ``nan_check_every`` updates have already been
+applied to non-finite gradients, i.e. the weights are invalid and the caller reloads the last checkpoint
+(``nan_check_every=1`` restores the reference's check-before-every-update cost and semantics: the check then runs
+before ``optimizer.step()``).
+
+``use_graph=True`` replays one captured HIP graph per step, so everything that shapes the step is frozen at capture:
+batch shapes (a different shape raises; run a last partial batch through a second, eager ``Trainer`` or drop it),
+constructor options that change control flow (dropout > 0, BatchNorm ``momentum=None``).  The learning rate is NOT
+frozen: it lives in a device tensor, change it with ``set_lr``.
 """
 from __future__ import annotations
 
@@ -22,7 +33,8 @@ import torch.distributed as dist
 
 from . import metrics
 from .checkpoint import EarlyStopping, checkpoint_name, history_entry, save_checkpoint
-from .dp import BucketedGradAllReduce, broadcast_parameters, coalesced_grad_mean
+from .dp import (NO_GROUP, BucketedGradAllReduce, broadcast_parameters, coalesced_grad_mean, group_active, group_rank,
+                 group_size)
 from .folds import LOSOJob, aggregate_folds, aggregate_seed_results, assign_jobs, loso_jobs
 
 GRAD_CLIP = 5.0                                             # train.py:235
@@ -33,15 +45,23 @@ class Trainer:
     def __init__(self, model: torch.nn.Module, lr: float = 2e-4, betas=DEFAULT_BETAS, weight_decay: float = 0.0,
                  weight_l1: float = 1.0, grad_clip: float = GRAD_CLIP, compute_dtype: Optional[torch.dtype] = torch.bfloat16,
                  use_graph: bool = False, bucket_bytes: int = 64 << 20, nan_check_every: int = 50, process_group=None,
-                 cond_encoder: Optional[torch.nn.Module] = None, noise_augmentor: Optional[torch.nn.Module] = None):
+                 cond_encoder: Optional[torch.nn.Module] = None, noise_augmentor: Optional[torch.nn.Module] = None,
+                 loss_fn: Optional[Callable] = None, normalize_target: Optional[Callable] = None):
+        """``loss_fn(pred, target)`` / ``normalize_target(target)`` default to the reference's step
+        (``weight_l1 * l1_crop_loss`` on the HIP kernels after ``per_channel_normalize``); the host-logic tests
+        pass plain torch callables so that the data-parallel protocol runs on CPU under gloo."""
         self.model = model
+        self._loss_fn = loss_fn
+        self._normalize = normalize_target or metrics.per_channel_normalize
         self.noise_augmentor = noise_augmentor    # train.py:2310-2328; applied to the input only, in train mode
         self.cond_encoder = cond_encoder          # train.py:2026-2030 (--conditioning spectro_temporal)
         if compute_dtype is not None and hasattr(model, "set_compute_dtype"):
             model.set_compute_dtype(compute_dtype)
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.world = group_size(process_group)
         broadcast_parameters(model, process_group=process_group)
+        if use_graph:       # the captured optimizer step reads lr from memory: schedulers keep working (set_lr)
+            lr = torch.tensor(float(lr), dtype=torch.float32, device=next(model.parameters()).device)
         groups = [{"params": list(model.parameters()), "lr": lr}]
         if cond_encoder is not None:
             broadcast_parameters(cond_encoder, process_group=process_group)
@@ -59,6 +79,15 @@ class Trainer:
         self._steps = 0
         self._bad = None
 
+    def set_lr(self, lr: float):
+        """Learning-rate change that also reaches a captured step (warm-up, cosine, ReduceLROnPlateau of the
+        reference's ``train()``): with ``use_graph`` the rate is a device tensor the graph reads on every replay."""
+        for g in self.opt.param_groups:
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(float(lr))
+            else:
+                g["lr"] = float(lr)
+
     def _cond(self, ob: torch.Tensor) -> Optional[torch.Tensor]:
         """train.py:1409-1414: the encoder runs in eval() (running BatchNorm statistics, no dropout) even while
         its weights train."""
@@ -72,6 +101,8 @@ class Trainer:
         return emb
 
     def _loss(self, pred, target):
+        if self._loss_fn is not None:
+            return self._loss_fn(pred, target)
         return metrics.l1_crop_loss(pred, target, self.weight_l1)
 
     def step(self, ob: torch.Tensor, target: torch.Tensor, odor_ids: Optional[torch.Tensor] = None,
@@ -81,7 +112,7 @@ class Trainer:
         if self.noise_augmentor is not None:      # train.py:1401-1402 (host-side coin flip: stays outside the graph)
             self.noise_augmentor.train()
             ob = self.noise_augmentor(ob)
-        tgt = metrics.per_channel_normalize(target)
+        tgt = self._normalize(target)
         if self.use_graph:
             cond = [cond_emb] if cond_emb is not None else ([odor_ids] if odor_ids is not None else [])
             if self._graphed is None:
@@ -106,6 +137,8 @@ class Trainer:
                     cond_emb = self._cond(ob)
             pred = self.model(ob, odor_ids, cond_emb=cond_emb) if cond_emb is not None else self.model(ob, odor_ids)
             loss = self._loss(pred, tgt)
+            if self.nan_check_every == 1 and not bool(torch.isfinite(loss.detach())):
+                raise ValueError("NaN/Inf detected in loss")      # train.py:1543-1544: before backward, weights intact
             loss.backward()
             self.reducer.finish()
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip)
@@ -147,9 +180,11 @@ class Trainer:
                 psd_diff.append(metrics.psd_diff_db_torch(pc, tc, fs=sampling_rate))
                 if diag is None:
                     diag = metrics.psd_diagnostics_torch(pc, tc, fs=sampling_rate)
-        if stats is None:
-            return {"mse": 0.0, "mae": 0.0, "corr": 0.0, "r2": 0.0}           # train.py:1061-1068
+        if stats is None:       # no batch on this rank: still join the collective the other ranks are in
+            stats = metrics.PooledStats(next(self.model.parameters()).device)
         stats.all_reduce(self.pg)
+        if float(stats.sums[0]) == 0.0:
+            return {"mse": 0.0, "mae": 0.0, "corr": 0.0, "r2": 0.0}           # train.py:1061-1068
         out = stats.finalize()
         if psd_err:
             out["psd_err_db"] = float(torch.stack(psd_err).mean())
@@ -197,7 +232,7 @@ class Trainer:
             if stopper.update(val_loss, epoch) and checkpoint_dir is not None:
                 save_checkpoint(self.model, self.opt, epoch, Path(checkpoint_dir) / checkpoint_name(config), config=config,
                                 data=data, process_group=self.pg)
-            if dist.is_available() and dist.is_initialized():
+            if group_active(self.pg):
                 dist.barrier(group=self.pg)
             history.append(history_entry(epoch, train_metrics, val_metrics))
             if stopper.should_stop(dev):
@@ -218,9 +253,13 @@ def run_loso(all_sessions: Sequence[str], run_fold: Callable[[LOSOJob], Dict[str
     test_avg_r2 / test_avg_corr / test_avg_delta of the results JSON, LOSO/runner.py:831-833).  Results
     are exchanged once (all_gather_object, host side) and aggregated as the reference does:
     mean over seeds per fold, then mean +- std over folds.
+
+    Ranks run DIFFERENT jobs (and possibly different numbers of them), so ``run_fold`` must not enter a collective
+    of ``process_group``: build its ``Trainer`` with ``process_group=dp.NO_GROUP`` (also what ``EarlyStopping`` /
+    ``save_checkpoint`` / ``PooledStats.all_reduce`` take), and give every job its own checkpoint directory.
     """
-    world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-    rank = dist.get_rank(process_group) if world > 1 else 0
+    world = group_size(process_group)
+    rank = group_rank(process_group)
     jobs = loso_jobs(all_sessions, seed, n_seeds, folds_to_run)
     mine = assign_jobs(jobs, world)[rank]
     local = [((j.fold_idx, j.seed_idx), run_fold(j)) for j in mine]
