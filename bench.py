@@ -5,12 +5,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): the train.py/LOSO default model
+Default workload (BASELINE.json configs[1]): the train.py/LOSO default model
 (in=out=32, base=256, conv_type=modern, attention none, gelu, skip add, batch norm,
 cross_attn_gated FiLM; 41,966,772 parameters), synthetic N(0,1) windows of 32 ch x 4096 samples,
 64 windows per GPU, bf16 kernels with fp32 master weights.  One step = forward + L1 on the
 [500:4500] crop + backward + bucketed gradient all-reduce (N>1) + grad-clip 5.0 + AdamW step,
 i.e. everything the reference's train_epoch does per batch (train.py:1395-1560).
+``--workload B2`` = the same with skip_type="concat" (optimal_config.json); ``--workload C`` = BASELINE.json
+configs[2], the wide ECoG stress (128 channels in/out, n_downsample=4, ladder 256-512-1024-2048-2048,
+446,645,540 parameters).
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- the dominant kernel (conv_fwd2_kernel: implicit-GEMM conv forward/data-grad on bf16
@@ -37,10 +40,17 @@ import torch.nn.functional as F
 CONFIG_B = dict(in_channels=32, out_channels=32, base=256, conv_type="modern", attention_type="none",
                 activation="gelu", skip_type="add", norm_type="batch", cond_mode="cross_attn_gated",
                 n_downsample=2)
+WORKLOADS = {
+    # name: (constructor overrides, algorithmic forward GFLOP per window, description)
+    "B": ({}, 122.339, "config B: CondUNet1D train.py/LOSO default (base=256, modern 4x dilated k7 + SE, FiLM, skip add, BN)"),
+    "B2": (dict(skip_type="concat"), 167.437, "config B2: config B with skip_type=concat (optimal_config.json)"),
+    "C": (dict(in_channels=128, out_channels=128, n_downsample=4), 472.178,
+          "config C: wide ECoG stress (128 ch in/out, n_downsample=4, ladder 256-512-1024-2048-2048, 446.6 M parameters)"),
+}
 T = 4096
 CROP = (500, 4500)
-GFLOP_PER_WINDOW_FWD = 122.339       # algorithmic conv FLOPs, config B
 BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+TRAFFIC_FILE = "r01_hbm_traffic.json"
 KERNEL_DESCR = {
     "conv_fwd2_kernel": "conv_fwd2_kernel_128/_192 (bf16 implicit-GEMM tap-list conv, forward and data-grad launches)",
     "conv_stream_kernel": "conv_stream_kernel (bf16 single-tap conv, persistent 256x128 tiles)",
@@ -55,10 +65,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="B", choices=sorted(WORKLOADS), help="B (default, the headline config), B2, C")
     ap.add_argument("--batch", type=int, default=64, help="windows per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-windows", type=int, default=16, help="windows per CPU-baseline step (3 steps are timed)")
+    ap.add_argument("--cpu-windows", type=int, default=8, help="windows per CPU-baseline step (1 warm-up + 3 timed steps "
+                    "at each thread count)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--conditioning", default="odor_onehot", choices=["odor_onehot", "spectro_temporal"],
                     help="spectro_temporal: the SpectroTemporalEncoder (train.py --conditioning default) runs inside the "
@@ -73,28 +85,51 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(n_windows: int, cfg=None):
-    """Oracle (CPU port of the reference path) on a bounded sample of the same workload."""
+def _cpu_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(n_windows: int, cfg, gflop_fwd: float):
+    """Oracle (CPU port of the reference path) on a bounded sample of the same workload, as BASELINE.md section 3
+    plans it: 1 warm-up step + 3 timed steps, median, at k = 8 threads (comparable with the 8-thread container
+    anchors of BASELINE.md) and at k = this process's CPU share (torch's default thread count: OMP_NUM_THREADS,
+    16 on a one-GPU box).  ``value`` is the larger thread count's."""
     from oracle import condunet_oracle as O
-    threads = torch.get_num_threads()
-    cfg = cfg or CONFIG_B
+    share = torch.get_num_threads()
     sd = O.init_state_dict(cfg, seed=0)
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
     run_sd = dict(sd)
     run_sd.update(leaves)
     g = torch.Generator().manual_seed(0)
-    ob = torch.randn(n_windows, 32, T, generator=g)
-    tgt = torch.randn(n_windows, 32, T, generator=g)
+    ob = torch.randn(n_windows, cfg["in_channels"], T, generator=g)
+    tgt = torch.randn(n_windows, cfg["out_channels"], T, generator=g)
     ids = torch.zeros(n_windows, dtype=torch.long)
-    reps = 3
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        loss = O.train_step_loss(run_sd, cfg, ob, tgt, odor_ids=ids)
-        loss.backward()
-    dt = time.perf_counter() - t0
-    return {"value": reps * n_windows / dt, "unit": "windows/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} fwd+bwd steps of config B on {n_windows} windows each (32ch x {T}), fp32 torch CPU ops, "
-                      f"{dt:.1f} s on {threads} threads"}
+    rates, total = {}, 0.0
+    for k in sorted({min(8, share), share}):
+        torch.set_num_threads(k)
+        times = []
+        for rep in range(4):                     # the first one is the warm-up
+            for v in leaves.values():
+                v.grad = None
+            t0 = time.perf_counter()
+            O.train_step_loss(run_sd, cfg, ob, tgt, odor_ids=ids).backward()
+            times.append(time.perf_counter() - t0)
+        total += sum(times)
+        rates[k] = n_windows / sorted(times[1:])[1]
+    torch.set_num_threads(share)
+    gf = 3 * gflop_fwd
+    return {"value": rates[share], "unit": "windows/s", "cores": share, "kind": "port",
+            "by_threads": {str(k): v for k, v in rates.items()},
+            "sample": f"fwd+bwd steps of the same config on {n_windows} windows each (fp32 torch CPU ops), 1 warm-up + 3 timed, "
+                      f"median, at " + " and ".join(f"{k} threads ({v:.2f} windows/s = {v * gf:.0f} GFLOP/s)" for k, v in rates.items())
+                      + f"; {total:.1f} s of CPU work on '{_cpu_name()}'"}
 
 
 def main():
@@ -118,7 +153,9 @@ def main():
     from unet_amd.dp import BucketedGradAllReduce, broadcast_parameters
 
     torch.manual_seed(0)
-    cfg = dict(CONFIG_B, attention_type=args.attention)
+    over, gflop_fwd, wl_descr = WORKLOADS[args.workload]
+    cfg = dict(CONFIG_B, attention_type=args.attention, **over)
+    c_in, c_out = cfg["in_channels"], cfg["out_channels"]
     model = unet_amd.CondUNet1D(**cfg)
     with torch.no_grad():  # the reference zero-initialises outc; give it values so backward is not trivially zero
         model.outc.weight.normal_(0, 0.02)
@@ -134,7 +171,7 @@ def main():
     groups = [{"params": list(model.parameters())}]
     if args.conditioning == "spectro_temporal":
         from unet_amd.cond import SpectroTemporalEncoder
-        enc = SpectroTemporalEncoder(in_channels=32, emb_dim=128).to(dev)
+        enc = SpectroTemporalEncoder(in_channels=c_in, emb_dim=128).to(dev)
         enc.set_compute_dtype(cdt)
         enc.eval()                                                         # train.py:1410-1411
         broadcast_parameters(enc)
@@ -144,8 +181,8 @@ def main():
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B = args.batch
-    ob = torch.randn(B, 32, T, device=dev, generator=g).to(cdt)
-    tgt = torch.randn(B, 32, T, device=dev, generator=g) * 1.7 + 0.3     # raw target batch
+    ob = torch.randn(B, c_in, T, device=dev, generator=g).to(cdt)
+    tgt = torch.randn(B, c_out, T, device=dev, generator=g) * 1.7 + 0.3     # raw target batch
     ids = torch.zeros(B, dtype=torch.long, device=dev)
 
     from unet_amd import metrics
@@ -217,6 +254,9 @@ def main():
         # region; profiles/ holds the rocprofv3 summary of the graph replay itself for cross-checking.
         ops.PROFILE = []
         for _ in range(min(3, args.steps)):
+            model.zero_grad(set_to_none=True)
+            if enc is not None:
+                enc.zero_grad(set_to_none=True)
             loss_fn(model(ob, ids, cond_emb=enc(ob)) if enc is not None else model(ob, ids), tgt).backward()
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
@@ -236,46 +276,50 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
         "data": "synthetic N(0,1) windows, random-init weights (reference init, seed 0)",
-        "config": {"workload": "config B: CondUNet1D train.py/LOSO default (base=256, modern 4x dilated k7 + SE, FiLM, "
-                               "skip add, BN), 32ch x 4096 windows, 64 windows/GPU, fwd + L1[500:4500] + bwd + "
+        "config": {"workload": wl_descr + f", {c_in}ch x {T} windows, {B} windows/GPU, fwd + L1[500:4500] + bwd + "
                                "grad all-reduce + clip 5.0 + AdamW", "windows_per_gpu": B, "params": n_params,
                    "parallelism": f"dp{world}", "launch": mode, "conditioning": args.conditioning,
                    "attention": args.attention},
         "final_loss": float(loss.item()), "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
         "ms_each_step": [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(args.steps)],
-        "model_tflops_algorithmic": value * 3 * GFLOP_PER_WINDOW_FWD / 1e3,
-        "frac_of_bf16_mfma_peak_end_to_end": value * 3 * GFLOP_PER_WINDOW_FWD / 1e3 / (BF16_DENSE_PEAK_TFLOPS * world),
+        "model_tflops_algorithmic": value * 3 * gflop_fwd / 1e3,
+        "frac_of_bf16_mfma_peak_end_to_end": value * 3 * gflop_fwd / 1e3 / (BF16_DENSE_PEAK_TFLOPS * world),
     }
     if prof:
         agg = {}
-        for kind, flops, e0, e1 in prof:
-            a = agg.setdefault(kind, [0.0, 0.0, 0])
+        for kind, flops, execf, e0, e1 in prof:
+            a = agg.setdefault(kind, [0.0, 0.0, 0, 0.0])
             a[0] += flops
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
+            a[3] += execf
         kern = {k: {"launches": v[2], "avg_us": 1e6 * v[1] / v[2], "tflops_algorithmic": v[0] / v[1] / 1e12,
-                    "ms_per_step": 1e3 * v[1] / prof_steps} for k, v in agg.items()}
+                    "tflops_executed": v[3] / v[1] / 1e12, "ms_per_step": 1e3 * v[1] / prof_steps} for k, v in agg.items()}
         # dominant kernel = the conv kernel with the largest share of the step (conv_fwd2_kernel: tiled
         # implicit-GEMM forward / data-grad); its HBM traffic per launch comes from the committed PMC passes
         dom_name = max(agg, key=lambda k: agg[k][1])
         dom = agg[dom_name]
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tpath) and B == 64 and args.dtype == "bf16":
+        tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+        if os.path.exists(tpath) and B == 64 and args.dtype == "bf16" and args.workload == "B":
             tk = json.load(open(tpath))["kernels"]
             hit = [v for k, v in tk.items() if k.startswith(dom_name)]
             if hit:
                 traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit)
-                traffic_src = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this step, FETCH_SIZE doubled for gfx950)"
+                traffic_src = f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this step, FETCH_SIZE doubled for gfx950)"
+        # achieved / frac price the kernel on the FLOPs it EXECUTES (23 merged taps); the reference algorithm's count
+        # (28 branch taps) is reported beside it and is what the windows/s-derived figures use
         out["roofline"] = {"bound": "mfma", "kernel": KERNEL_DESCR.get(dom_name, dom_name),
-                           "achieved": dom[0] / dom[1] / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": dom[0] / dom[1] / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                           "achieved": dom[3] / dom[1] / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": dom[3] / dom[1] / 1e12 / BF16_DENSE_PEAK_TFLOPS,
+                           "achieved_algorithmic": dom[0] / dom[1] / 1e12,
+                           "frac_algorithmic": dom[0] / dom[1] / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
                            "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                           "flops_per_launch_algorithmic": dom[0] / dom[2],
+                           "flops_per_launch_algorithmic": dom[0] / dom[2], "flops_per_launch_executed": dom[3] / dom[2],
                            "avg_launch_us": 1e6 * dom[1] / dom[2], "launches": dom[2], "timing": timing_mode}
         out["kernels"] = kern
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_windows, cfg)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_windows if args.workload != "C" else max(1, args.cpu_windows // 4), cfg, gflop_fwd)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -58,7 +58,7 @@ def _f32c(t: Tensor) -> Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
-# When set to a list, every MFMA conv launch appends (kind, algorithmic FLOPs, start event, end event);
+# When set to a list, every MFMA conv launch appends (kind, algorithmic FLOPs, executed FLOPs, start event, end event);
 # bench.py uses it to time the dominant kernel live, on the stream the kernels are launched on.
 PROFILE: Optional[list] = None
 
@@ -69,18 +69,21 @@ _VARIANTS = {1: "conv_fwd_kernel", 2: "conv_fwd2_kernel", 3: "conv_stream_kernel
 
 
 class _Timed:
-    def __init__(self, kind: str, flops: float):
+    def __init__(self, kind: str, flops: float, alg_scale: float = 1.0):
+        """flops: the reference algorithm's count (28 taps for the merged dilated conv); flops / alg_scale is what
+        the kernel executes (23 merged taps)."""
         self.on = PROFILE is not None
         if self.on:
-            self.rec = (kind, flops, torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.rec = (kind, flops, flops / alg_scale, torch.cuda.Event(enable_timing=True),
+                        torch.cuda.Event(enable_timing=True))
 
     def __enter__(self):
         if self.on:
-            self.rec[2].record()
+            self.rec[3].record()
 
     def __exit__(self, *exc):
         if self.on:
-            self.rec[3].record()
+            self.rec[4].record()
             variant = _VARIANTS.get(int(_lib.load().unet_conv1d_last_variant()), self.rec[0])
             PROFILE.append((variant,) + self.rec[1:])
 
@@ -266,7 +269,7 @@ def conv_forward_raw(geom: ConvGeom, x1: Tensor, x2: Optional[Tensor], w_packed:
     else:
         y = torch.empty((x1.shape[0], l_out, c_out), dtype=x1.dtype, device=x1.device)
     d = _desc(geom, x1, x2, y, res, act)
-    with _Timed("conv_fwd", geom.alg_flops(d.n, l_out, c_out, d.c1 + d.c2)):
+    with _Timed("conv_fwd", geom.alg_flops(d.n, l_out, c_out, d.c1 + d.c2), geom.alg_scale):
         check(lib.unet_conv1d_fwd(C.byref(d), _p(x1), _p(x2), _p(w_packed), _p(bias), _p(res), _p(y), _stream()),
               "unet_conv1d_fwd")
     return y
@@ -281,7 +284,7 @@ def conv_wgrad_raw(geom: ConvGeom, x1: Tensor, x2: Optional[Tensor], dy: Tensor,
     ws_bytes = lib.unet_conv1d_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=dy.device)
     dw = torch.empty((geom.n_taps, c_out, ctot), dtype=torch.float32, device=dy.device)
-    with _Timed("conv_wgrad", geom.alg_flops(n, dy.shape[1], c_out, ctot)):
+    with _Timed("conv_wgrad", geom.alg_flops(n, dy.shape[1], c_out, ctot), geom.alg_scale):
         check(lib.unet_conv1d_wgrad(C.byref(d), _p(x1), _p(x2), _p(dy), _p(dw), _p(ws), ws_bytes, _stream()),
               "unet_conv1d_wgrad")
     return dw
