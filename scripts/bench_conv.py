@@ -112,6 +112,64 @@ def main():
             print(f"{name:9s} dgrad+wgrad  sequential {res['seq']:8.1f} us   two streams {res['conc']:8.1f} us "
                   f"({100 * (res['conc'] / res['seq'] - 1):+.1f} %)", flush=True)
             continue
+        if args.kind == "glue":      # weight-grad (MFMA-bound) beside the HBM-bound row kernels of a block's backward
+            d = ops._desc(geom, x, None, dy, None)
+            ws_bytes = lib.unet_conv1d_wgrad_workspace_bytes(C.byref(d))
+            ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=dev)
+            dw = torch.empty((geom.n_taps, cout, cin), dtype=torch.float32, device=dev)
+            wgrad = lambda: _lib.check(lib.unet_conv1d_wgrad(C.byref(d), ops._p(x), None, ops._p(dy), ops._p(dw), ops._p(ws),
+                                                             ws_bytes, ops._stream()), "wgrad")
+            y = torch.randn(n, l_out, cout, device=dev).to(dt)
+            dz = torch.randn(n, l_out, cout, device=dev).to(dt)
+            o1, o2 = torch.empty_like(y), torch.empty_like(y)
+            a = torch.rand(n, cout, device=dev) + 0.5
+            b = torch.randn(n, cout, device=dev) * 0.1
+            p1, p2 = ops._part_buf(y, 2)
+            st = ops._stream
+
+            def glue():      # ~ SE-excite bwd, BN/GELU bwd reduce + apply, gated-add bwd: 11 tensor touches
+                _lib.check(lib.unet_scale_bwd(ops._dt(y), ops._p(y), ops._p(dz), ops._p(a), ops._p(o1), ops._p(p1), n, l_out, cout, st()), "s")
+                _lib.check(lib.unet_affine_act_bwd_reduce(ops._dt(y), ops._p(y), ops._p(o1), None, ops._p(a), ops._p(b), 3, ops._p(p1), ops._p(p2), n, l_out, cout, st()), "r")
+                _lib.check(lib.unet_affine_act_bwd_apply(ops._dt(y), ops._p(y), ops._p(o1), None, ops._p(a), ops._p(b), 3, ops._p(a), ops._p(b), ops._p(b), ops._p(o2), n, l_out, cout, st()), "a")
+                _lib.check(lib.unet_gated_add_bwd(ops._dt(y), ops._p(y), ops._p(dz), ops._p(a), ops._p(o1), ops._p(p1), ops._p(p2), n, l_out, cout, st()), "g")
+
+            side = torch.cuda.Stream()
+            main_s = torch.cuda.current_stream()
+
+            def seq():
+                wgrad()
+                glue()
+
+            def conc():
+                side.wait_stream(main_s)
+                with torch.cuda.stream(side):
+                    wgrad()
+                glue()
+                main_s.wait_stream(side)
+
+            def conc2():     # row kernels dispatched first
+                side.wait_stream(main_s)
+                glue()
+                with torch.cuda.stream(side):
+                    wgrad()
+                main_s.wait_stream(side)
+
+            res = {}
+            for label, fn in (("wgrad", wgrad), ("glue", glue), ("seq", seq), ("conc", conc), ("conc2", conc2)):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                res[label] = e0.elapsed_time(e1) * 1e3 / args.iters
+            print(f"{name:9s} wgrad {res['wgrad']:7.1f}  glue {res['glue']:7.1f}  sequential {res['seq']:7.1f}  two streams "
+                  f"{res['conc']:7.1f} us ({100 * (res['conc'] / res['seq'] - 1):+.1f} %)  glue-first {res['conc2']:7.1f} us "
+                  f"({100 * (res['conc2'] / res['seq'] - 1):+.1f} %)", flush=True)
+            continue
         for k in kinds:
             if k == "fwd":
                 wp = ops.pack_weights(w, ops._dt(x), transpose=False, tap_src=None, n_taps=geom.n_taps, row_lo=0,
