@@ -175,6 +175,14 @@ int unet_affine_act_bwd_apply(int32_t dtype, const void* y, const void* dz, cons
                               const float* cb, const float* cc, void* dy, int32_t n, int32_t rows,
                               int32_t c, void* stream);
 
+/* ... the same, also emitting dy_sum_part = partial column sums of dy: the bias gradient of the conv that produced y
+ * (models.py:558, 692-699: nn.Conv1d bias), which otherwise costs a pass of its own over dy (unet_colsum).
+ * dy_sum_part NULL = plain unet_affine_act_bwd_apply. */
+int unet_affine_act_bwd_apply_sum(int32_t dtype, const void* y, const void* dz, const float* dpool,
+                                  const float* a, const float* b, int32_t act, const float* ca,
+                                  const float* cb, const float* cc, void* dy, float* dy_sum_part, int32_t n,
+                                  int32_t rows, int32_t c, void* stream);
+
 /* out = x * s[n][c]  (SE excite, models.py:662);  bwd: dx = dout*s, ds_part = sum_t dout*x */
 int unet_scale_fwd(int32_t dtype, const void* x, const float* s, void* out, int32_t n, int32_t rows,
                    int32_t c, void* stream);

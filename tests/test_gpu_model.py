@@ -196,3 +196,50 @@ def test_config_b_shape_vs_oracle():
             assert worst < tol_g, (dtype, worst)
         else:
             _check_bf16_grads({k: p.grad for k, p in params.items()}, refg, tol_g)
+
+
+def test_bias_gradients_come_from_the_norm_backward_hand_off():
+    """The conv bias gradients in front of a norm / activation are taken from the column sums the norm's backward
+    emits with dy (ops._offer_colsum / _take_colsum) instead of a separate pass over dy -- and they are the right
+    numbers (golden gradients of every conv bias, incl. the bottleneck convs whose bias gradient is not zero)."""
+    from unet_amd import ops
+    g = Golden("B_modern_add_bn_gelu")
+    model = _build(g)
+    model.train()
+    before = ops.BIAS_HINT_HITS
+    pred = model(g.t("ob").cuda(), **_kw(g))
+    F.l1_loss(pred[..., g.lo:g.hi], g.t("target").cuda()[..., g.lo:g.hi]).backward()
+    assert ops.BIAS_HINT_HITS - before >= 7          # 5 block convs + 2 bottleneck convs
+    params = dict(model.named_parameters())
+    for k in ("mid.0.bias", "mid.2.bias"):
+        assert rel(params[k].grad, g.t("grad/" + k)) < 1e-3, k
+    assert not ops._BIAS_HINT or len(ops._BIAS_HINT) <= 64
+
+
+def test_inference_reuses_packed_weights_until_a_parameter_changes():
+    """Under torch.no_grad() the packed weight images are cached per conv and revalidated against the parameters'
+    version counters: same output call after call with no repacking, and an in-place weight update is seen."""
+    from unet_amd import ops
+    g = Golden("B2_modern_concat")
+    model = _build(g, torch.bfloat16)
+    model.eval()
+    ob = g.t("ob").cuda()
+    ops.clear_pack_cache()
+    with torch.no_grad():
+        y0 = model(ob, **_kw(g))
+        n_entries = len(ops._PACK_CACHE)
+        assert n_entries >= 10
+        snapshot = {k: v[1][0].data_ptr() for k, v in ops._PACK_CACHE.items()}
+        y1 = model(ob, **_kw(g))
+        assert torch.equal(y0, y1)
+        assert {k: v[1][0].data_ptr() for k, v in ops._PACK_CACHE.items()} == snapshot     # nothing was repacked
+        model.outc.weight.mul_(2.0)                                                       # bumps the version counter
+        model.decoders[0].block.conv[0].scale_weights.add_(0.3)
+        y2 = model(ob, **_kw(g))
+        assert len(ops._PACK_CACHE) == n_entries
+    assert rel(y2, y0) > 1e-3
+    # and the cached path computes what the training-mode path (no cache) computes from the same weights
+    with torch.enable_grad():
+        y3 = model(ob, **_kw(g))
+    assert torch.equal(y3.detach(), y2)
+    ops.clear_pack_cache()

@@ -43,8 +43,24 @@ __global__ __launch_bounds__(THREADS) void rowstream_kernel(OP op, int rows, int
     if (active) {
       typename OP::State st;
       op.init(st, n, cg * V, c);
-      for (int r = r_begin + rl; r < r_end; r += RL)
-        op.row(st, ((long long)n * rows + r) * c + cg * V, acc);
+      // U rows per iteration, all of their loads issued before the first use: a thread walks only rows / (parts * RL)
+      // rows (16 at C = 256), and with one row in flight per thread the pass is latency-bound (the two pure reductions
+      // ran at 3.5 TB/s); with four it is bandwidth-bound
+      constexpr int U = OP::UNROLL, NIN = OP::NIN;
+      const long long base = ((long long)n * rows) * c + cg * V;
+      int r = r_begin + rl;
+      for (; r + (U - 1) * RL < r_end; r += U * RL) {
+        float in[U][NIN][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) op.ld(base + (long long)(r + u * RL) * c, in[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) op.row(st, base + (long long)(r + u * RL) * c, in[u], acc);
+      }
+      for (; r < r_end; r += RL) {
+        float in[NIN][V];
+        op.ld(base + (long long)r * c, in);
+        op.row(st, base + (long long)r * c, in, acc);
+      }
     }
     if constexpr (NR > 0) {
 #pragma unroll
@@ -71,6 +87,7 @@ __global__ __launch_bounds__(THREADS) void rowstream_kernel(OP op, int rows, int
 
 template <typename T, int V_> struct OpBase {
   static constexpr int V = V_;
+  static constexpr int UNROLL = 4;      // rows in flight per thread (an op with heavy per-element math may lower it)
   __device__ static __forceinline__ void ldc(const float* p, float (&f)[V_]) {
 #pragma unroll
     for (int i = 0; i < V_; ++i) f[i] = p[i];
@@ -83,15 +100,14 @@ template <typename T, int V_> struct OpBase {
 
 // ---- s1 = sum y, s2 = sum y^2 ------------------------------------------------------------------
 template <typename T, int V_> struct RowStatsOp : OpBase<T, V_> {
-  static constexpr int NRED = 2;
+  static constexpr int NRED = 2, NIN = 1;
   const T* y; float* s1; float* s2;
   struct State {};
   __device__ void init(State&, int, int, int) const {}
-  __device__ void row(State&, long long e, float (&acc)[2][V_]) const {
-    float f[V_];
-    VecIO<T, V_>::load(y + e, f);
+  __device__ void ld(long long e, float (&in)[1][V_]) const { VecIO<T, V_>::load(y + e, in[0]); }
+  __device__ void row(State&, long long, const float (&in)[1][V_], float (&acc)[2][V_]) const {
 #pragma unroll
-    for (int i = 0; i < V_; ++i) { acc[0][i] += f[i]; acc[1][i] += f[i] * f[i]; }
+    for (int i = 0; i < V_; ++i) { acc[0][i] += in[0][i]; acc[1][i] += in[0][i] * in[0][i]; }
   }
   __device__ void write_part(long long e, const float (&s)[2][V_]) const {
     this->stc(s1 + e, s[0]); this->stc(s2 + e, s[1]);
@@ -100,33 +116,32 @@ template <typename T, int V_> struct RowStatsOp : OpBase<T, V_> {
 
 // ---- column sum --------------------------------------------------------------------------------
 template <typename T, int V_> struct ColSumOp : OpBase<T, V_> {
-  static constexpr int NRED = 1;
+  static constexpr int NRED = 1, NIN = 1;
   const T* x; float* out;
   struct State {};
   __device__ void init(State&, int, int, int) const {}
-  __device__ void row(State&, long long e, float (&acc)[1][V_]) const {
-    float f[V_];
-    VecIO<T, V_>::load(x + e, f);
+  __device__ void ld(long long e, float (&in)[1][V_]) const { VecIO<T, V_>::load(x + e, in[0]); }
+  __device__ void row(State&, long long, const float (&in)[1][V_], float (&acc)[1][V_]) const {
 #pragma unroll
-    for (int i = 0; i < V_; ++i) acc[0][i] += f[i];
+    for (int i = 0; i < V_; ++i) acc[0][i] += in[0][i];
   }
   __device__ void write_part(long long e, const float (&s)[1][V_]) const { this->stc(out + e, s[0]); }
 };
 
 // ---- z = act(a*y+b), pool = sum z -----------------------------------------------------------------
 template <typename T, int V_, bool POOL> struct AffineActFwdOp : OpBase<T, V_> {
-  static constexpr int NRED = POOL ? 1 : 0;
+  static constexpr int NRED = POOL ? 1 : 0, NIN = 1;
   const T* y; T* z; const float* a; const float* b; float* pool; int act;
   struct State { float a[V_], b[V_]; };
   __device__ void init(State& s, int n, int c0, int c) const {
     this->ldc(a + (long long)n * c + c0, s.a); this->ldc(b + (long long)n * c + c0, s.b);
   }
-  __device__ void row(State& s, long long e, float (&acc)[POOL ? 1 : 1][V_]) const {
+  __device__ void ld(long long e, float (&in)[1][V_]) const { VecIO<T, V_>::load(y + e, in[0]); }
+  __device__ void row(State& s, long long e, const float (&in)[1][V_], float (&acc)[POOL ? 1 : 1][V_]) const {
     float f[V_];
-    VecIO<T, V_>::load(y + e, f);
 #pragma unroll
     for (int i = 0; i < V_; ++i) {
-      f[i] = act_fwd(act, s.a[i] * f[i] + s.b[i]);
+      f[i] = act_fwd(act, s.a[i] * in[0][i] + s.b[i]);
       if (POOL) acc[0][i] += f[i];
     }
     VecIO<T, V_>::store(z + e, f);
@@ -135,9 +150,11 @@ template <typename T, int V_, bool POOL> struct AffineActFwdOp : OpBase<T, V_> {
 };
 
 // ---- backward of the above ---------------------------------------------------------------------
-template <typename T, int V_, bool APPLY> struct AffineActBwdOp : OpBase<T, V_> {
-  static constexpr int NRED = APPLY ? 0 : 2;
+template <typename T, int V_, bool APPLY, bool BSUM = false> struct AffineActBwdOp : OpBase<T, V_> {
+  static constexpr int NRED = APPLY ? (BSUM ? 1 : 0) : 2, NIN = 2;
+  static constexpr int UNROLL = APPLY ? 4 : 2;   // the reduce pass at 4 rows crosses 128 VGPRs and loses a wave per SIMD (measured +10 %)
   const T* y; const T* dz; const float* dpool; const float* a; const float* b; int act;
+  float* dysum;                               // apply with BSUM: per-part column sums of dy (the producing conv's bias gradient)
   float* g1; float* g2;                       // reduce
   const float* ca; const float* cb; const float* cc; T* dy;  // apply
   struct State { float a[V_], b[V_], dp[V_], ca[V_], cb[V_], cc[V_]; };
@@ -151,50 +168,57 @@ template <typename T, int V_, bool APPLY> struct AffineActBwdOp : OpBase<T, V_> 
     }
     if (APPLY) { this->ldc(ca + o, s.ca); this->ldc(cb + o, s.cb); this->ldc(cc + o, s.cc); }
   }
-  __device__ void row(State& s, long long e, float (&acc)[APPLY ? 1 : 2][V_]) const {
-    float fy[V_], fd[V_];
-    VecIO<T, V_>::load(y + e, fy);
-    VecIO<T, V_>::load(dz + e, fd);
+  __device__ void ld(long long e, float (&in)[2][V_]) const {
+    VecIO<T, V_>::load(y + e, in[0]);
+    VecIO<T, V_>::load(dz + e, in[1]);
+  }
+  __device__ void row(State& s, long long e, const float (&in)[2][V_], float (&acc)[APPLY ? 1 : 2][V_]) const {
     float out[V_];
 #pragma unroll
     for (int i = 0; i < V_; ++i) {
-      const float g = (fd[i] + s.dp[i]) * act_bwd(act, s.a[i] * fy[i] + s.b[i]);
-      if (APPLY) out[i] = s.ca[i] * g + s.cb[i] * fy[i] + s.cc[i];
-      else { acc[0][i] += g; acc[1][i] += g * fy[i]; }
+      const float fy = in[0][i];
+      const float g = (in[1][i] + s.dp[i]) * act_bwd(act, s.a[i] * fy + s.b[i]);
+      if (APPLY) {
+        out[i] = s.ca[i] * g + s.cb[i] * fy + s.cc[i];
+        if (BSUM) acc[0][i] += out[i];
+      } else { acc[0][i] += g; acc[1][i] += g * fy; }
     }
     if (APPLY) VecIO<T, V_>::store(dy + e, out);
   }
-  __device__ void write_part(long long e, const float (&s)[2][V_]) const {
-    this->stc(g1 + e, s[0]); this->stc(g2 + e, s[1]);
+  __device__ void write_part(long long e, const float (&s)[APPLY ? 1 : 2][V_]) const {
+    if (APPLY) { if (BSUM) this->stc(dysum + e, s[0]); }
+    else { this->stc(g1 + e, s[0]); this->stc(g2 + e, s[APPLY ? 0 : 1]); }
   }
 };
 
 // ---- out = x*s ;  dx = dout*s, ds = sum dout*x ----------------------------------------------------
 template <typename T, int V_> struct ScaleFwdOp : OpBase<T, V_> {
-  static constexpr int NRED = 0;
+  static constexpr int NRED = 0, NIN = 1;
   const T* x; T* out; const float* s;
   struct State { float s[V_]; };
   __device__ void init(State& st, int n, int c0, int c) const { this->ldc(s + (long long)n * c + c0, st.s); }
-  __device__ void row(State& st, long long e, float (&)[1][V_]) const {
+  __device__ void ld(long long e, float (&in)[1][V_]) const { VecIO<T, V_>::load(x + e, in[0]); }
+  __device__ void row(State& st, long long e, const float (&in)[1][V_], float (&)[1][V_]) const {
     float f[V_];
-    VecIO<T, V_>::load(x + e, f);
 #pragma unroll
-    for (int i = 0; i < V_; ++i) f[i] *= st.s[i];
+    for (int i = 0; i < V_; ++i) f[i] = in[0][i] * st.s[i];
     VecIO<T, V_>::store(out + e, f);
   }
   __device__ void write_part(long long, const float (&)[1][V_]) const {}
 };
 template <typename T, int V_> struct ScaleBwdOp : OpBase<T, V_> {
-  static constexpr int NRED = 1;
+  static constexpr int NRED = 1, NIN = 2;
   const T* x; const T* dout; T* dx; const float* s; float* ds;
   struct State { float s[V_]; };
   __device__ void init(State& st, int n, int c0, int c) const { this->ldc(s + (long long)n * c + c0, st.s); }
-  __device__ void row(State& st, long long e, float (&acc)[1][V_]) const {
-    float fx[V_], fd[V_];
-    VecIO<T, V_>::load(x + e, fx);
-    VecIO<T, V_>::load(dout + e, fd);
+  __device__ void ld(long long e, float (&in)[2][V_]) const {
+    VecIO<T, V_>::load(x + e, in[0]);
+    VecIO<T, V_>::load(dout + e, in[1]);
+  }
+  __device__ void row(State& st, long long e, const float (&in)[2][V_], float (&acc)[1][V_]) const {
+    float fd[V_];
 #pragma unroll
-    for (int i = 0; i < V_; ++i) { acc[0][i] += fd[i] * fx[i]; fd[i] *= st.s[i]; }
+    for (int i = 0; i < V_; ++i) { acc[0][i] += in[1][i] * in[0][i]; fd[i] = in[1][i] * st.s[i]; }
     VecIO<T, V_>::store(dx + e, fd);
   }
   __device__ void write_part(long long e, const float (&sm)[1][V_]) const { this->stc(ds + e, sm[0]); }
@@ -202,34 +226,38 @@ template <typename T, int V_> struct ScaleBwdOp : OpBase<T, V_> {
 
 // ---- out = res + g*o ;  d_o = g*dout, dg = sum dout*o ----------------------------------------------
 template <typename T, int V_> struct GatedAddFwdOp : OpBase<T, V_> {
-  static constexpr int NRED = 0;
+  static constexpr int NRED = 0, NIN = 2;
   const T* res; const T* o; T* out; const float* g;
   struct State { float g[V_]; };
   __device__ void init(State& st, int n, int c0, int c) const { this->ldc(g + (long long)n * c + c0, st.g); }
-  __device__ void row(State& st, long long e, float (&)[1][V_]) const {
-    float fr[V_], fo[V_];
-    VecIO<T, V_>::load(res + e, fr);
-    VecIO<T, V_>::load(o + e, fo);
+  __device__ void ld(long long e, float (&in)[2][V_]) const {
+    VecIO<T, V_>::load(res + e, in[0]);
+    VecIO<T, V_>::load(o + e, in[1]);
+  }
+  __device__ void row(State& st, long long e, const float (&in)[2][V_], float (&)[1][V_]) const {
+    float fr[V_];
 #pragma unroll
-    for (int i = 0; i < V_; ++i) fr[i] += st.g[i] * fo[i];
+    for (int i = 0; i < V_; ++i) fr[i] = in[0][i] + st.g[i] * in[1][i];
     VecIO<T, V_>::store(out + e, fr);
   }
   __device__ void write_part(long long, const float (&)[1][V_]) const {}
 };
 // SUM: also the per-part column sums of d_o (the bias gradient of the conv that produced o), saving a pass over d_o
 template <typename T, int V_, bool SUM> struct GatedAddBwdOp : OpBase<T, V_> {
-  static constexpr int NRED = SUM ? 2 : 1;
+  static constexpr int NRED = SUM ? 2 : 1, NIN = 2;
   const T* o; const T* dout; T* d_o; const float* g; float* dg; float* dsum;
   struct State { float g[V_]; };
   __device__ void init(State& st, int n, int c0, int c) const { this->ldc(g + (long long)n * c + c0, st.g); }
-  __device__ void row(State& st, long long e, float (&acc)[SUM ? 2 : 1][V_]) const {
-    float fo[V_], fd[V_];
-    VecIO<T, V_>::load(o + e, fo);
-    VecIO<T, V_>::load(dout + e, fd);
+  __device__ void ld(long long e, float (&in)[2][V_]) const {
+    VecIO<T, V_>::load(o + e, in[0]);
+    VecIO<T, V_>::load(dout + e, in[1]);
+  }
+  __device__ void row(State& st, long long e, const float (&in)[2][V_], float (&acc)[SUM ? 2 : 1][V_]) const {
+    float fd[V_];
 #pragma unroll
     for (int i = 0; i < V_; ++i) {
-      acc[0][i] += fd[i] * fo[i];
-      fd[i] *= st.g[i];
+      acc[0][i] += in[1][i] * in[0][i];
+      fd[i] = in[1][i] * st.g[i];
       if (SUM) acc[SUM ? 1 : 0][i] += fd[i];
     }
     VecIO<T, V_>::store(d_o + e, fd);
@@ -797,7 +825,7 @@ extern "C" int unet_affine_act_bwd_reduce(int32_t dtype, const void* y, const vo
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH_ROWS(dtype, c, PL(y, dz), {
     AffineActBwdOp<T, V, false> op; op.y = (const T*)y; op.dz = (const T*)dz; op.dpool = dpool; op.a = a; op.b = b;
-    op.act = act; op.g1 = g1_part; op.g2 = g2_part; op.ca = op.cb = op.cc = nullptr; op.dy = nullptr;
+    op.act = act; op.g1 = g1_part; op.g2 = g2_part; op.ca = op.cb = op.cc = nullptr; op.dy = nullptr; op.dysum = nullptr;
     return launch_rows(op, n, rows, c, st, "affine_act_bwd_reduce");
   });
   return 0;
@@ -812,8 +840,24 @@ extern "C" int unet_affine_act_bwd_apply(int32_t dtype, const void* y, const voi
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH_ROWS(dtype, c, PL(y, dz, dy), {
     AffineActBwdOp<T, V, true> op; op.y = (const T*)y; op.dz = (const T*)dz; op.dpool = dpool; op.a = a; op.b = b;
-    op.act = act; op.g1 = op.g2 = nullptr; op.ca = ca; op.cb = cb; op.cc = cc; op.dy = (T*)dy;
+    op.act = act; op.g1 = op.g2 = nullptr; op.ca = ca; op.cb = cb; op.cc = cc; op.dy = (T*)dy; op.dysum = nullptr;
     return launch_rows(op, n, rows, c, st, "affine_act_bwd_apply");
+  });
+  return 0;
+}
+
+extern "C" int unet_affine_act_bwd_apply_sum(int32_t dtype, const void* y, const void* dz, const float* dpool,
+                                             const float* a, const float* b, int32_t act, const float* ca,
+                                             const float* cb, const float* cc, void* dy, float* dy_sum_part, int32_t n,
+                                             int32_t rows, int32_t c, void* stream) {
+  if (!dy_sum_part) return unet_affine_act_bwd_apply(dtype, y, dz, dpool, a, b, act, ca, cb, cc, dy, n, rows, c, stream);
+  if (check_dims(n, rows, c, "affine_act_bwd_apply_sum")) return -1;
+  UNET_REQUIRE(y && dz && a && b && ca && cb && cc && dy, "affine_act_bwd_apply_sum: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH_ROWS(dtype, c, PL(y, dz, dy), {
+    AffineActBwdOp<T, V, true, true> op; op.y = (const T*)y; op.dz = (const T*)dz; op.dpool = dpool; op.a = a; op.b = b;
+    op.act = act; op.g1 = op.g2 = nullptr; op.ca = ca; op.cb = cb; op.cc = cc; op.dy = (T*)dy; op.dysum = dy_sum_part;
+    return launch_rows(op, n, rows, c, st, "affine_act_bwd_apply_sum");
   });
   return 0;
 }

@@ -397,7 +397,8 @@ class ConvBlock(nn.Module):
     def _main_conv(self, x1: Tensor, x2: Optional[Tensor]) -> Tensor:
         c = self.conv[0]
         l_out = ops.conv_out_len(x1.shape[1], 3, self.stride)
-        return ops.conv(x1, c.weight.permute(2, 0, 1), c.bias, ops.geom_conv(3, self.stride), l_out, x2=x2)
+        return ops.conv(x1, c.weight.permute(2, 0, 1), c.bias, ops.geom_conv(3, self.stride), l_out, x2=x2,
+                        params=(c.weight, c.bias))
 
     def forward_nlc(self, x1: Tensor, emb: Optional[Tensor], x2: Optional[Tensor] = None) -> Tensor:
         y = self._main_conv(x1, x2)
@@ -482,10 +483,9 @@ class MultiScaleDilatedConv1d(nn.Module):
         return w_eff, b_eff
 
     def forward_nlc(self, x1: Tensor, x2: Optional[Tensor] = None) -> Tensor:
-        w_eff, b_eff = self.effective_weights()
         k, s = self.kernel_size, self.stride
         l_out = ops.conv_out_len(x1.shape[1], k, s, 1)
-        return ops.conv(x1, w_eff, b_eff, self._geom, l_out, x2=x2)
+        return ops.conv(x1, self.effective_weights, None, self._geom, l_out, x2=x2, params=tuple(self.parameters()))
 
     def forward(self, x: Tensor) -> Tensor:
         return _as_ncl(self.forward_nlc(_to_nlc(x)))
@@ -532,16 +532,21 @@ class _UpMixin:
 
     def _up_forward(self, x: Tensor, skip: Tensor, emb: Optional[Tensor]) -> Tensor:
         geom, kidx = ops.geom_convt_k4s2p1()
-        wk = self.up.weight.permute(2, 1, 0)                      # [k, Cout, Cin] view
-        w = torch.stack([wk[k] for k in kidx])                    # tap order (no index tensor: graph-capture safe)
+
+        def w():                                                   # tap order (no index tensor: graph-capture safe)
+            wk = self.up.weight.permute(2, 1, 0)                   # [k, Cout, Cin] view
+            return torch.stack([wk[k] for k in kidx]), self.up.bias
+
+        up_params = (self.up.weight, self.up.bias)
         l_up = 2 * x.shape[1]
         l_skip = skip.shape[1]
         if self.skip_type == "add" and self.skip_proj is not None:
-            skip = ops.conv(skip, self.skip_proj.weight.permute(2, 0, 1), self.skip_proj.bias, ops.geom_conv(1), l_skip)
+            skip = ops.conv(skip, self.skip_proj.weight.permute(2, 0, 1), self.skip_proj.bias, ops.geom_conv(1), l_skip,
+                            params=(self.skip_proj.weight, self.skip_proj.bias))
         if self.skip_type == "add" and l_up == l_skip:
-            u = ops.conv(x, w, self.up.bias, geom, l_up, res=skip)
+            u = ops.conv(x, w, None, geom, l_up, res=skip, params=up_params)
             return self.block.forward_nlc(u, emb)
-        u = ops.conv(x, w, self.up.bias, geom, l_up)
+        u = ops.conv(x, w, None, geom, l_up, params=up_params)
         if l_up < l_skip:
             s = (l_skip - l_up) // 2
             skip = skip[:, s:s + l_up, :]
@@ -628,7 +633,7 @@ class _Bottleneck(nn.Sequential):
     def forward_nlc(self, x: Tensor) -> Tensor:
         for m in self:
             if isinstance(m, nn.Conv1d):
-                x = ops.conv(x, m.weight.permute(2, 0, 1), m.bias, ops.geom_conv(3), x.shape[1])
+                x = ops.conv(x, m.weight.permute(2, 0, 1), m.bias, ops.geom_conv(3), x.shape[1], params=(m.weight, m.bias))
             else:
                 x = m.forward_nlc(x)
         return x
@@ -792,6 +797,15 @@ class CondUNet1D(nn.Module):
 
     def set_gradient_checkpointing(self, enable: bool = True):
         self.gradient_checkpointing = enable
+
+    def train(self, mode: bool = True):
+        """Entering training mode drops the inference cache of packed weights (``ops.conv``): fused optimizers update
+        parameters WITHOUT bumping their version counters (torch's fused AdamW), so version checks alone would let
+        an ``eval()`` after further training steps run on stale images.  Weights changed by such an optimizer while
+        the model stays in eval mode need an explicit ``ops.clear_pack_cache()``."""
+        if mode:
+            ops.clear_pack_cache()
+        return super().train(mode)
 
     def set_compute_dtype(self, dtype: Optional[torch.dtype]):
         """bf16 or fp32 kernels regardless of the input dtype (None = follow the input)."""
@@ -992,14 +1006,17 @@ class CondUNet1D(nn.Module):
         if self.use_residual:
             res = x0
         else:
-            res = ops.conv(x0, self.residual_conv.weight.permute(2, 0, 1), self.residual_conv.bias, ops.geom_conv(1), l)
+            res = ops.conv(x0, self.residual_conv.weight.permute(2, 0, 1), self.residual_conv.bias, ops.geom_conv(1), l,
+                           params=(self.residual_conv.weight, self.residual_conv.bias))
         if self.outc._forward_hooks or self.outc._forward_pre_hooks:
             # a hook on outc must see delta before the residual (models.py:3359-3366): unfused
             def outc_delta(_blk, xin):
-                return ops.conv(xin, self.outc.weight.permute(2, 0, 1), self.outc.bias, ops.geom_conv(3), l)
+                return ops.conv(xin, self.outc.weight.permute(2, 0, 1), self.outc.bias, ops.geom_conv(3), l,
+                                params=(self.outc.weight, self.outc.bias))
             out_nlc = _HookedCall.run(self.outc, outc_delta, x) + res
         else:
-            out_nlc = ops.conv(x, self.outc.weight.permute(2, 0, 1), self.outc.bias, ops.geom_conv(3), l, res=res)
+            out_nlc = ops.conv(x, self.outc.weight.permute(2, 0, 1), self.outc.bias, ops.geom_conv(3), l, res=res,
+                               params=(self.outc.weight, self.outc.bias))
         out = ops.ToNCLFn.apply(out_nlc, io_dtype)
         if self.use_adaptive_scaling:
             out = self.adaptive_scaler(out, raw_input)

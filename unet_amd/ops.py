@@ -10,6 +10,7 @@ All activations here are "NLC": contiguous ``[N, L, C]`` (channels last), dtype 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -300,6 +301,30 @@ def conv_dgrad_raw(geom: ConvGeom, wf: Tensor, dy: Tensor, l_in: int, row_lo: in
     return conv_forward_raw(gd, dy, None, wp, None, res, l_in, rows, out=out)
 
 
+# Bias-gradient hand-off.  The backward pass of norm + activation writes the gradient `dy` of a conv's output and can
+# add its per-part column sums for free (unet_affine_act_bwd_apply_sum); the conv's backward would otherwise spend a
+# pass of its own over dy (unet_colsum) on the bias gradient.  The partials travel beside the tensor: keyed by the
+# Python object's id and guarded by a weak reference, so an entry can only ever be used with the very tensor it was
+# computed from (a dead or recycled object never matches; the fallback is the separate pass).
+import weakref
+
+_BIAS_HINT = {}
+BIAS_HINT_HITS = 0          # diagnostic: how many conv bias gradients came from a hand-off
+
+
+def _offer_colsum(dy: Tensor, parts: Tensor):
+    if len(_BIAS_HINT) > 64:
+        _BIAS_HINT.clear()
+    _BIAS_HINT[id(dy)] = (weakref.ref(dy), parts)
+
+
+def _take_colsum(dy: Tensor) -> Optional[Tensor]:
+    h = _BIAS_HINT.pop(id(dy), None)
+    if h is not None and h[0]() is dy and h[1].shape[0] == dy.shape[0] and h[1].shape[2] == dy.shape[2]:
+        return h[1]
+    return None
+
+
 class ConvFn(torch.autograd.Function):
     """y = conv(geom; [x1 | x2], w[J, Cout, C1+C2], bias) (+ res).  See include/unet_hip.h."""
 
@@ -329,8 +354,10 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        global BIAS_HINT_HITS
         x1, x2, wf = ctx.saved_tensors
         geom: ConvGeom = ctx.geom
+        hint = _take_colsum(dy)
         dy = dy.contiguous()
         n, l_in, c1 = x1.shape
         c2 = x2.shape[2] if x2 is not None else 0
@@ -339,7 +366,11 @@ class ConvFn(torch.autograd.Function):
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = dy
         if ctx.has_bias and ctx.needs_input_grad[3]:
-            db = colsum(dy)
+            if hint is not None:
+                db = _reduce_all_parts(hint)
+                BIAS_HINT_HITS += 1
+            else:
+                db = colsum(dy)
         if ctx.needs_input_grad[2]:
             dw = conv_wgrad_raw(geom, x1, x2, dy, c_out)
             if ctx.w_dtype != torch.float32:
@@ -351,9 +382,64 @@ class ConvFn(torch.autograd.Function):
         return dx1, dx2, dw, db, dres, None, None
 
 
-def conv(x1: Tensor, w: Tensor, bias: Optional[Tensor], geom: ConvGeom, l_out: int, x2: Optional[Tensor] = None,
-         res: Optional[Tensor] = None) -> Tensor:
-    return ConvFn.apply(x1, x2, w, bias, res, geom, l_out)
+# Packed-weight cache for INFERENCE.  A training step must repack every weight (the optimizer has just changed it; the
+# packed bf16 image is a per-call temporary), but under torch.no_grad() the same weights serve call after call
+# (sliding-window inference, evaluate()): the packed image is then kept per conv, keyed on the identity of the
+# parameters it derives from and revalidated against their ``_version`` counters ("packed-weight caches
+# are torch tensors owned by the Python module, rebuilt when weight._version changes").  Version counters are not
+# enough on their own -- torch's FUSED optimizers update parameters without bumping them -- so CondUNet1D.train()
+# also drops the cache whenever the model (re-)enters training mode.  Never used while a HIP graph is being
+# captured: a cache hit would leave the pack kernels out of the graph, and replays would run on stale images.
+_PACK_CACHE = {}
+
+
+def clear_pack_cache():
+    _PACK_CACHE.clear()
+
+
+def _cacheable(params) -> bool:
+    return (params is not None and not torch.is_grad_enabled() and os.environ.get("UNET_PACK_CACHE", "1") != "0"
+            and not torch.cuda.is_current_stream_capturing())
+
+
+def packed_for_inference(tag, params: Sequence[Tensor], dtype: int, build):
+    """``build()`` -> tuple of tensors (packed weights, fp32 bias, ...) derived from ``params``; cached per
+    (tag, dtype, parameter identities) while every parameter's ``_version`` is unchanged."""
+    key = (tag, dtype) + tuple(p.data_ptr() for p in params)
+    versions = tuple(p._version for p in params)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == versions:
+        return hit[1]
+    val = build()
+    _PACK_CACHE[key] = (versions, val)
+    return val
+
+
+def conv(x1: Tensor, w, bias: Optional[Tensor], geom: ConvGeom, l_out: int, x2: Optional[Tensor] = None,
+         res: Optional[Tensor] = None, params: Optional[Sequence[Tensor]] = None) -> Tensor:
+    """``w``: [J, Cout, C1+C2] weights, or a callable returning ``(w, bias)`` (weights that take work to derive: the
+    merged dilated taps, the transposed conv's tap order).  ``params``: the parameters ``w`` and ``bias`` derive
+    from; given, inference calls reuse the packed image instead of rebuilding it (see above)."""
+    if _cacheable(params):
+        _need_cuda(x1)
+        x1 = _nlc_ok(x1)
+        x2 = _nlc_ok(x2) if x2 is not None else None
+        res = _nlc_ok(res) if res is not None else None
+        dt = _dt(x1)
+        c1, c2 = x1.shape[2], (x2.shape[2] if x2 is not None else 0)
+
+        def build():
+            wv, bv = w() if callable(w) else (w, bias)
+            wf = wv.detach().float()
+            if wf.shape[0] != geom.n_taps or wf.shape[2] != c1 + c2:
+                raise ValueError(f"weight {tuple(wf.shape)} does not fit taps={geom.n_taps}, channels={c1}+{c2}")
+            wp = pack_weights(wf, dt, transpose=False, tap_src=None, n_taps=wf.shape[0], row_lo=0, rows=wf.shape[1], c1=c1, c2=c2)
+            return wp, (_f32c(bv) if bv is not None else None), wf.shape[1]
+
+        wp, b32, c_out = packed_for_inference(("conv", geom, c1, c2), params, dt, build)
+        return conv_forward_raw(geom, x1, x2, wp, b32, res, l_out, c_out)
+    wv, bv = w() if callable(w) else (w, bias)
+    return ConvFn.apply(x1, x2, wv, bv, res, geom, l_out)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -499,9 +585,11 @@ class AffineActFn(torch.autograd.Function):
         dy = None
         if ctx.needs_input_grad[0]:
             dy = torch.empty_like(y)
-            check(lib.unet_affine_act_bwd_apply(_dt(y), _p(y), _p(dz), _p(dp), _p(a), _p(b), ctx.act_id, _p(ca),
-                                                _p(cb), _p(cc), _p(dy), n, rows, c, _stream()),
-                  "unet_affine_act_bwd_apply")
+            (bsum,) = _part_buf(y)
+            check(lib.unet_affine_act_bwd_apply_sum(_dt(y), _p(y), _p(dz), _p(dp), _p(a), _p(b), ctx.act_id, _p(ca),
+                                                    _p(cb), _p(cc), _p(dy), _p(bsum), n, rows, c, _stream()),
+                  "unet_affine_act_bwd_apply_sum")
+            _offer_colsum(dy, bsum)
         return dy, dgamma, dbeta, None, None, None
 
 
@@ -556,8 +644,9 @@ class BatchNormActFn(torch.autograd.Function):
                                        _p(cf[0]), _p(cf[1]), _p(cf[2]), _p(dgb[0]), _p(dgb[1]), st),
               "unet_bn_finalize_bwd")
         dy = torch.empty_like(y)
-        check(lib.unet_affine_act_bwd_apply(dt, _p(y), _p(dz), _p(dp), _p(a), _p(b), ctx.act_id, _p(cf[0]), _p(cf[1]),
-                                            _p(cf[2]), _p(dy), n, rows, c, st), "unet_affine_act_bwd_apply")
+        check(lib.unet_affine_act_bwd_apply_sum(dt, _p(y), _p(dz), _p(dp), _p(a), _p(b), ctx.act_id, _p(cf[0]), _p(cf[1]),
+                                                _p(cf[2]), _p(dy), _p(g1p), n, rows, c, st), "unet_affine_act_bwd_apply_sum")
+        _offer_colsum(dy, g1p)       # g1p is free again: bn_finalize_bwd has consumed it
         dgamma = dgb[0].to(ctx.gdtype) if ctx.has_affine else None
         dbeta = dgb[1].to(ctx.gdtype) if ctx.has_affine else None
         return dy, dgamma, dbeta, None, None, None, None, None, None
@@ -667,12 +756,16 @@ class FilmFn(torch.autograd.Function):
         g1 = geom_conv(1)
         wqf, wof = wq.detach().float(), wo.detach().float()          # [1, C, C] views of the 1x1 conv weights
         kf, vf, gf = _f32c(kk), _f32c(v), _f32c(g)
-        q = conv_forward_raw(g1, z, None, pack_weights(wqf, dt, transpose=False, tap_src=None, n_taps=1, row_lo=0,
-                                                       rows=c, c1=c, c2=0), _f32c(bq), None, rows, c)
+        pk = lambda wf: pack_weights(wf, dt, transpose=False, tap_src=None, n_taps=1, row_lo=0, rows=c, c1=c, c2=0)
+        if _cacheable((wq, bq, wo, bo)):
+            wqp, bq32, wop, bo32 = packed_for_inference(("film", c), (wq, bq, wo, bo), dt,
+                                                        lambda: (pk(wqf), _f32c(bq), pk(wof), _f32c(bo)))
+        else:
+            wqp, bq32, wop, bo32 = pk(wqf), _f32c(bq), pk(wof), _f32c(bo)
+        q = conv_forward_raw(g1, z, None, wqp, bq32, None, rows, c)
         h = torch.empty_like(q)
         check(lib.unet_film_softmax_fwd(dt, _p(q), _p(kf), _p(vf), _p(h), n, rows, c, st), "unet_film_softmax_fwd")
-        o = conv_forward_raw(g1, h, None, pack_weights(wof, dt, transpose=False, tap_src=None, n_taps=1, row_lo=0,
-                                                       rows=c, c1=c, c2=0), _f32c(bo), None, rows, c)
+        o = conv_forward_raw(g1, h, None, wop, bo32, None, rows, c)
         out = torch.empty_like(z)
         check(lib.unet_gated_add_fwd(dt, _p(z), _p(o), _p(gf), _p(out), n, rows, c, st), "unet_gated_add_fwd")
         ctx.save_for_backward(z, q, h, o, wqf, wof, kf, vf, gf)
