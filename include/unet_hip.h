@@ -222,6 +222,35 @@ int unet_merge_taps_bwd(const float* const* w_branch_host, const float* sw, int3
                         float* const* dw_branch_host, float* dsw_part, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Per-window vector algebra (csrc/small.hip): the Linear layers on [windows][channels] vectors -- FiLM's k_proj /
+ * v_proj / gate (models.py:493-494, 497-500, 506-509) and the SqueezeExcitation MLP (models.py:650-655, 660-661).
+ * A group of up to UNET_SMALL_MAX maps is one launch each way (a BLAS call + elementwise ops per map were ~45
+ * launches per block and step).  All tensors fp32, row-major: x [n][n_in], w [n_out][n_in], y / pre / dy [n][n_out].
+ *   fwd:  pre = scale * (x w^T + b) ; y = act(pre)          (b, pre nullable)
+ *   bwd:  dpre = dy * act'(.) * scale  (GELU' from pre, sigmoid' from y) ;
+ *         dw [n_out][n_in] = dpre^T x ; db [n_out] = sum_n dpre ;
+ *         dx_part [slot][n][n_in], slot = dx_slot0 + (output tile index): the input gradient contributed by each
+ *         16-output tile; the caller adds the slots (unet_reduce_rows) -- unet_small_linear_tiles(n_out) per problem.
+ *         dw / db / dx_part nullable.
+ * ---------------------------------------------------------------------------------- */
+#define UNET_SMALL_MAX 4
+enum { UNET_SMALL_NONE = 0, UNET_SMALL_GELU = 1, UNET_SMALL_SIGMOID = 2 };
+typedef struct UnetSmallLinear {
+  const float* x; const float* w; const float* b;
+  float* y; float* pre;
+  float* part;                  /* fwd, when unet_small_linear_splits(n_in) > 1: [splits][n][n_out] partial sums */
+  int32_t n_in, n_out, act;
+  float scale;
+  const float* dy;
+  float* dw; float* db; float* dx_part;
+  int32_t dx_slot0;
+} UnetSmallLinear;
+int unet_small_linear_fwd(const UnetSmallLinear* problems_host, int32_t n_problems, int32_t n, void* stream);
+int unet_small_linear_bwd(const UnetSmallLinear* problems_host, int32_t n_problems, int32_t n, void* stream);
+int32_t unet_small_linear_tiles(int32_t n_out);
+int32_t unet_small_linear_splits(int32_t n_in);
+
+/* ------------------------------------------------------------------------------------
  * Loss / evaluation reductions (csrc/metrics.hip).  Inputs are NCL rows: row r starts at
  * base + r*ld (elements), time is the contiguous axis.  fp64 results, no host sync.
  * ---------------------------------------------------------------------------------- */

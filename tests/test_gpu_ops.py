@@ -231,3 +231,38 @@ def test_zscore_boundary(in_dtype):
     assert rel(obd.grad, obr.grad) < (1e-4 if in_dtype == torch.float32 else 1e-2)
     y = ops.ToNCLFn.apply(x.detach(), torch.float32)
     assert torch.equal(y, x.detach().permute(0, 2, 1))
+
+
+@pytest.mark.parametrize("dims", [(2, 16, (8, 8, 8)), (64, 128, (256, 256, 256)), (70, 100, (130, 33, 64)), (5, 1024, (256,)),
+                                  (130, 40, (1024, 72))])
+def test_small_linear_group(dims):
+    """Grouped Linear maps of one [N, I] input (FiLM k/v/gate, SE MLP; csrc/small.hip) against torch fp32: forward,
+    input gradient (sum of the per-tile partials), weight and bias gradients; ragged sizes, N beyond one tile."""
+    ops = _ops()
+    n, n_in, outs = dims
+    torch.manual_seed(n + n_in)
+    x = torch.randn(n, n_in)
+    acts = ["none", "sigmoid", "gelu", "none"]
+    maps, ref_params = [], []
+    for i, o in enumerate(outs):
+        w = torch.randn(o, n_in) / n_in ** 0.5
+        b = torch.randn(o) * 0.3 if i % 2 == 0 else None
+        ref_params.append((w.clone().requires_grad_(True), None if b is None else b.clone().requires_grad_(True)))
+        maps.append((w.cuda().requires_grad_(True), None if b is None else b.cuda().requires_grad_(True), acts[i], 0.5 + 0.25 * i))
+    xr = x.clone().requires_grad_(True)
+    refs = []
+    for (w, b), m in zip(ref_params, maps):
+        pre = m[3] * F.linear(xr, w, b)
+        refs.append({"none": pre, "sigmoid": torch.sigmoid(pre), "gelu": F.gelu(pre)}[m[2]])
+    gys = [torch.randn(r.shape) for r in refs]
+    sum((r * g).sum() for r, g in zip(refs, gys)).backward()
+    xd = x.cuda().requires_grad_(True)
+    ys = ops.small_linear_group(xd, maps)
+    sum((y * g.cuda()).sum() for y, g in zip(ys, gys)).backward()
+    for y, r in zip(ys, refs):
+        assert rel(y, r) < 2e-6
+    assert rel(xd.grad, xr.grad) < 1e-5
+    for (w, b), m in zip(ref_params, maps):
+        assert rel(m[0].grad, w.grad) < 1e-5
+        if b is not None:
+            assert rel(m[1].grad, b.grad) < 1e-5

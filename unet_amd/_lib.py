@@ -33,6 +33,17 @@ class ConvDesc(C.Structure):
     ]
 
 
+class SmallLinear(C.Structure):
+    """Mirror of UnetSmallLinear (include/unet_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p), ("pre", C.c_void_p),
+                ("part", C.c_void_p), ("n_in", C.c_int32), ("n_out", C.c_int32), ("act", C.c_int32), ("scale", C.c_float),
+                ("dy", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("dx_part", C.c_void_p),
+                ("dx_slot0", C.c_int32)]
+
+
+SMALL_MAX = 4
+SMALL_ACT = {"none": 0, "gelu": 1, "sigmoid": 2}
+
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _row_args = [_i32, _i32, _i32, _vp]  # n, rows, c, stream
 
@@ -72,6 +83,10 @@ _SIGNATURES = {
     "unet_merge_taps_fwd": (C.c_int, [C.POINTER(_vp), _vp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _vp, _vp]),
     "unet_merge_taps_bwd": (C.c_int, [C.POINTER(_vp), _vp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _vp,
                                       C.POINTER(_vp), _vp, _vp]),
+    "unet_small_linear_fwd": (C.c_int, [C.POINTER(SmallLinear), _i32, _i32, _vp]),
+    "unet_small_linear_bwd": (C.c_int, [C.POINTER(SmallLinear), _i32, _i32, _vp]),
+    "unet_small_linear_tiles": (_i32, [_i32]),
+    "unet_small_linear_splits": (_i32, [_i32]),
     "unet_pair_moments": (C.c_int, [_i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
     "unet_sum_rows_f64": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "unet_l1_crop_bwd": (C.c_int, [_i32, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _f32, _vp, _vp]),

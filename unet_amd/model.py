@@ -366,11 +366,13 @@ class FiLM(nn.Module):
     def forward_nlc(self, x: Tensor, emb: Optional[Tensor]) -> Tensor:
         if self.cond_mode == "none" or emb is None:
             return x
-        emb = emb.float()
-        kk = self.k_proj(emb) * self.scale_factor
-        v = self.v_proj(emb)
+        # k_proj (with the C^-1/2 of models.py:514 folded in), v_proj and the sigmoid gate: one launch for the three
+        gate = self.gate[0]
+        kk, v, g = ops.small_linear_group(emb, ((self.k_proj.weight, self.k_proj.bias, "none", self.scale_factor),
+                                                (self.v_proj.weight, self.v_proj.bias, "none", 1.0),
+                                                (gate.weight, gate.bias, "sigmoid", 1.0)))
         return ops.FilmFn.apply(x, self.q_proj.weight.permute(2, 0, 1), self.q_proj.bias,
-                                self.out_proj.weight.permute(2, 0, 1), self.out_proj.bias, kk, v, self.gate(emb))
+                                self.out_proj.weight.permute(2, 0, 1), self.out_proj.bias, kk, v, g)
 
     def forward(self, x: Tensor, emb: Optional[Tensor] = None) -> Tensor:
         if self.cond_mode == "none" or emb is None:
@@ -432,7 +434,11 @@ class SqueezeExcitation1D(nn.Module):
                                 nn.Linear(reduced, channels, bias=False), nn.Sigmoid())
 
     def gate_from_pool(self, pool_sum: Tensor, rows: int) -> Tensor:
-        return self.fc(pool_sum / rows)
+        """sigmoid(W2 gelu(W0 (pool_sum / rows))): two launches (models.py:660-661; the mean's 1/rows is the first
+        map's scale)."""
+        (h,) = ops.small_linear_group(pool_sum, ((self.fc[0].weight, None, "gelu", 1.0 / rows),))
+        (s,) = ops.small_linear_group(h, ((self.fc[2].weight, None, "sigmoid", 1.0),))
+        return s
 
     def forward(self, x: Tensor) -> Tensor:
         xn = _to_nlc(x)

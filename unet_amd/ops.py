@@ -800,6 +800,108 @@ class FilmFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
+# per-window vector algebra: groups of small Linear layers (csrc/small.hip)
+# ---------------------------------------------------------------------------------------------
+class SmallLinearGroupFn(torch.autograd.Function):
+    """y_p = act_p(scale_p * (x W_p^T + b_p)) for up to 4 Linear maps of ONE input x [N, I]: FiLM's k_proj / v_proj /
+    gate on the conditioning embedding (models.py:506-509) and the SE excitation MLP (models.py:660-661).  One launch
+    forward, one backward (+ the sum of the input-gradient partials), fp32."""
+
+    @staticmethod
+    def forward(ctx, x, acts: Tuple[int, ...], scales: Tuple[float, ...], *wb):
+        lib = _lib.load()
+        _need_cuda(x)
+        np_ = len(acts)
+        if np_ < 1 or np_ > _lib.SMALL_MAX or len(wb) != 2 * np_:
+            raise ValueError("1..4 (weight, bias) pairs")
+        xf = _f32c(x)
+        n, n_in = xf.shape
+        ws = [_f32c(wb[2 * i]) for i in range(np_)]
+        bs = [(_f32c(wb[2 * i + 1]) if wb[2 * i + 1] is not None else None) for i in range(np_)]
+        ys, pres = [], []
+        splits = int(lib.unet_small_linear_splits(n_in))
+        parts = []          # split-K partial sums of wide maps, consumed by the finishing launch
+        probs = (_lib.SmallLinear * np_)()
+        for i in range(np_):
+            n_out = ws[i].shape[0]
+            if ws[i].shape[1] != n_in:
+                raise ValueError(f"weight {tuple(ws[i].shape)} does not take {n_in} inputs")
+            y = torch.empty((n, n_out), dtype=torch.float32, device=xf.device)
+            pre = torch.empty_like(y) if acts[i] == _lib.SMALL_ACT["gelu"] else None
+            q = probs[i]
+            q.x, q.w, q.b, q.y, q.pre = xf.data_ptr(), ws[i].data_ptr(), (bs[i].data_ptr() if bs[i] is not None else None), \
+                y.data_ptr(), (pre.data_ptr() if pre is not None else None)
+            q.n_in, q.n_out, q.act, q.scale = n_in, n_out, acts[i], float(scales[i])
+            if splits > 1:
+                parts.append(torch.empty((splits, n, n_out), dtype=torch.float32, device=xf.device))
+                q.part = parts[-1].data_ptr()
+            ys.append(y)
+            pres.append(pre)
+        check(lib.unet_small_linear_fwd(probs, np_, n, _stream()), "unet_small_linear_fwd")
+        ctx.acts, ctx.scales, ctx.np = acts, scales, np_
+        ctx.has_b = [b is not None for b in bs]
+        ctx.has_pre = [p is not None for p in pres]
+        ctx.dtypes = (x.dtype,) + tuple(t.dtype if t is not None else None for t in wb)
+        ctx.save_for_backward(xf, *ws, *ys, *[p for p in pres if p is not None])
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = _lib.load()
+        np_ = ctx.np
+        saved = ctx.saved_tensors
+        xf, ws, ys = saved[0], saved[1:1 + np_], saved[1 + np_:1 + 2 * np_]
+        pres_it = iter(saved[1 + 2 * np_:])
+        n, n_in = xf.shape
+        need_x = ctx.needs_input_grad[0]
+        tiles = [int(lib.unet_small_linear_tiles(w.shape[0])) for w in ws]
+        dx_part = torch.empty((sum(tiles), n * n_in), dtype=torch.float32, device=xf.device) if need_x else None
+        probs = (_lib.SmallLinear * np_)()
+        keep, dws, dbs, slot = [], [], [], 0
+        for i in range(np_):
+            n_out = ws[i].shape[0]
+            dy = dys[i]
+            dy = torch.zeros((n, n_out), dtype=torch.float32, device=xf.device) if dy is None else _f32c(dy)
+            pre = next(pres_it) if ctx.has_pre[i] else None
+            dw = torch.empty_like(ws[i]) if ctx.needs_input_grad[3 + 2 * i] else None
+            db = torch.empty(n_out, dtype=torch.float32, device=xf.device) if (ctx.has_b[i] and ctx.needs_input_grad[4 + 2 * i]) else None
+            q = probs[i]
+            q.x, q.w, q.b, q.y, q.pre = xf.data_ptr(), ws[i].data_ptr(), None, ys[i].data_ptr(), (pre.data_ptr() if pre is not None else None)
+            q.n_in, q.n_out, q.act, q.scale = n_in, n_out, ctx.acts[i], float(ctx.scales[i])
+            q.dy = dy.data_ptr()
+            q.dw = dw.data_ptr() if dw is not None else None
+            q.db = db.data_ptr() if db is not None else None
+            q.dx_part = dx_part.data_ptr() if need_x else None
+            q.dx_slot0 = slot
+            slot += tiles[i]
+            keep.append(dy)
+            dws.append(dw)
+            dbs.append(db)
+        check(lib.unet_small_linear_bwd(probs, np_, n, _stream()), "unet_small_linear_bwd")
+        dx = None
+        if need_x:
+            dx = torch.empty((n, n_in), dtype=torch.float32, device=xf.device)
+            check(lib.unet_reduce_rows(_p(dx_part), dx_part.shape[0], n * n_in, _p(dx), _stream()), "unet_reduce_rows")
+            dx = dx.to(ctx.dtypes[0])
+        out = [dx, None, None]
+        for i in range(np_):
+            wd, bd = ctx.dtypes[1 + 2 * i], ctx.dtypes[2 + 2 * i]
+            out.append(dws[i].to(wd) if dws[i] is not None else None)
+            out.append(dbs[i].to(bd) if dbs[i] is not None else None)
+        return tuple(out)
+
+
+def small_linear_group(x: Tensor, maps) -> Tuple[Tensor, ...]:
+    """maps: sequence of (weight [O, I], bias [O] | None, activation "none" | "gelu" | "sigmoid", scale)."""
+    acts = tuple(_lib.SMALL_ACT[m[2]] for m in maps)
+    scales = tuple(float(m[3]) for m in maps)
+    wb = []
+    for m in maps:
+        wb += [m[0], m[1]]
+    return SmallLinearGroupFn.apply(x, acts, scales, *wb)
+
+
+# ---------------------------------------------------------------------------------------------
 # model boundary: NCL <-> NLC with the z-score of models.py:3235 fused into the way in
 # ---------------------------------------------------------------------------------------------
 def ncl_moments(x: Tensor, eps: float) -> Tuple[Tensor, Tensor]:
