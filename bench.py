@@ -80,6 +80,9 @@ def parse():
                          "headline config B has none")
     ap.add_argument("--graph", action="store_true", help="replay the captured HIP graph also for N > 1 (all-reduce runs "
                     "between the two graphs, not overlapped); default for N > 1 is the eager hook-driven path")
+    ap.add_argument("--graph-overlap", action="store_true", help="N > 1: ONE captured graph with the bucket all-reduces "
+                    "inside it, forked off the backward stream (graphs.GraphedTrainStep(overlap=True)); falls back to the "
+                    "eager hook-driven path if the capture is refused")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one (hook-driven overlapped "
                     "all-reduce) instead of replaying the captured HIP graph")
     return ap.parse_args()
@@ -138,7 +141,7 @@ def main():
     # N > 1: kernels are launched one by one so that each gradient bucket's RCCL all-reduce starts from its autograd
     # hook and overlaps the rest of backward (the host enqueues a step in ~18 ms, the GPU needs ~28 ms, so the
     # launches stay ahead); the captured graph has no such overlap (fwd+bwd graph -> all-reduce -> update graph).
-    if world > 1 and not args.graph:
+    if world > 1 and not (args.graph or args.graph_overlap):
         args.eager = True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -198,8 +201,8 @@ def main():
             from unet_amd.graphs import GraphedTrainStep
             fwd = (lambda o, i: model(o, i, cond_emb=enc(o))) if enc is not None else None
             graphed = GraphedTrainStep(model, loss_fn, opt, [ob, ids], [tgt], clip_norm=5.0, forward=fwd,
-                                       extra_modules=[enc] if enc is not None else [])
-            mode = "hipgraph"
+                                       extra_modules=[enc] if enc is not None else [], overlap=args.graph_overlap)
+            mode = "hipgraph+rccl-in-graph" if graphed.overlap else "hipgraph"
         except Exception as e:  # capture unsupported in this environment: run the same step eagerly
             import traceback
             traceback.print_exc()

@@ -47,7 +47,7 @@ def group_rank(process_group=None) -> int:
 
 class BucketedGradAllReduce:
     def __init__(self, params, bucket_bytes: int = 64 << 20, process_group=None, average: bool = True,
-                 tail_bytes: int = 4 << 20):
+                 tail_bytes: int = 4 << 20, force: bool = False):
         """``tail_bytes``: the parameters registered first (embedding, ``inc``) produce their gradients last, and the
         bucket that holds them is launched when backward has nothing left to overlap it with; they get a bucket of
         their own of at most this size, so the exposed message is a few MiB instead of a full bucket."""
@@ -55,6 +55,7 @@ class BucketedGradAllReduce:
         self.pg = process_group
         self.average = average
         self.world = group_size(process_group)
+        self.force = force and dist.is_available() and dist.is_initialized()   # issue the collectives in a one-rank group too
         self.buckets: List[torch.Tensor] = []
         self._groups: List[List[torch.nn.Parameter]] = []
         self._views: List[List[torch.Tensor]] = []
@@ -94,7 +95,7 @@ class BucketedGradAllReduce:
         self._expected = [len(g) for g in self._groups]
         self._pending = list(self._expected)
         self._launched = [False] * len(self._groups)
-        if self.world > 1:
+        if self.world > 1 or self.force:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -113,7 +114,7 @@ class BucketedGradAllReduce:
             self._launch(b)
 
     def _launch(self, b: int):
-        if self.world == 1 or self._launched[b]:
+        if (self.world == 1 and not self.force) or self._launched[b]:
             return
         self._launched[b] = True
         flat, group, views = self.buckets[b], self._groups[b], self._views[b]

@@ -10,8 +10,16 @@ stream, which is the capture stream during capture).
 Single process:   [ zero-grad | forward | loss | backward | clip | optimizer ]      = one graph
 Data parallel:    [ forward | loss | backward ] graph  ->  bucket pack + RCCL all-reduce (eager,
                   outside any graph)  ->  [ clip | optimizer ] graph
-(The eager path -- ``BucketedGradAllReduce`` hooks -- overlaps the all-reduce with backward instead;
-``GraphedTrainStep`` trades that overlap for zero launch overhead.)
+                  (``overlap=False``: no overlap of communication with backward)
+Data parallel, ``overlap=True``: ONE graph that contains the collectives.  The step is captured with the
+                  ``BucketedGradAllReduce`` hooks armed: when the last gradient of a bucket is produced inside the
+                  captured backward, the hook packs the bucket and issues its all-reduce asynchronously (RCCL runs it
+                  on the process group's own stream; the capture records that as a fork from the backward stream), and
+                  the wait is captured only in front of the clip.  In the replayed graph the collective of bucket k
+                  therefore depends on bucket k's gradients alone and runs beside the kernels of bucket k+1 -- graph
+                  replay AND overlap.  RCCL collectives are capturable (torch.distributed keeps captured work off the
+                  watchdog); if the capture is refused the constructor raises and the caller falls back to the eager
+                  hook-driven path (``bench.py`` does).
 """
 from __future__ import annotations
 
@@ -20,7 +28,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
-from .dp import _has_avg, group_size
+from .dp import BucketedGradAllReduce, _has_avg, group_size
 
 
 class GraphedTrainStep:
@@ -33,7 +41,8 @@ class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, loss_fn: Callable, optimizer: torch.optim.Optimizer,
                  inputs: Sequence[torch.Tensor], targets: Sequence[torch.Tensor], clip_norm: Optional[float] = None,
                  warmup: int = 3, process_group=None, bucket_bytes: int = 64 << 20,
-                 forward: Optional[Callable] = None, extra_modules: Sequence[torch.nn.Module] = ()):
+                 forward: Optional[Callable] = None, extra_modules: Sequence[torch.nn.Module] = (),
+                 overlap: bool = False, force_collectives: bool = False):
         """``extra_modules``: small modules trained in the same step (the conditioning encoder).  As in the
         reference (train.py:1553-1558) each gets its own clip, applied per rank BEFORE its gradients are averaged,
         whereas the model's clip follows the all-reduce."""
@@ -45,6 +54,10 @@ class GraphedTrainStep:
         self.static_tg = [t.clone() for t in targets]
         self.pg = process_group
         self.world = group_size(process_group)
+        self.overlap = overlap and (self.world > 1 or force_collectives)
+        if self.overlap:
+            self._init_overlapped(forward, bucket_bytes, warmup, force_collectives)
+            return
 
         def fwd_bwd():
             out = (forward or model)(*self.static_in)
@@ -90,6 +103,39 @@ class GraphedTrainStep:
             self.graph_update = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_update):
                 update()
+
+    # -- data parallel, collectives inside the graph ----------------------------------------------
+    def _init_overlapped(self, forward, bucket_bytes: int, warmup: int, force: bool):
+        """``force``: arm the hooks and issue the collectives also in a one-rank group (how the capture path is
+        exercised on a single GPU: tests/test_gpu_dp_graph.py)."""
+        if self.extra_params:
+            raise NotImplementedError("overlap=True with extra modules: their per-rank clip precedes their own small "
+                                      "all-reduce (train.py:1553-1558); use overlap=False or the eager path")
+        model, loss_fn = self.model, self.loss_fn
+        self.reducer = BucketedGradAllReduce(self.model_params, bucket_bytes, self.pg, force=force)
+
+        def full_step():
+            self.reducer.zero_grad()
+            out = (forward or model)(*self.static_in)
+            loss = loss_fn(out, *self.static_tg)
+            loss.backward()                      # bucket hooks fire in here: pack + async all-reduce per bucket
+            self.reducer.finish()                # the only wait on the collectives
+            if self.clip is not None:
+                torch.nn.utils.clip_grad_norm_(self.model_params, self.clip)
+            self.opt.step()
+            return loss
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                full_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = full_step()
+        self.graph_update = None
 
     # -- data-parallel pieces (eager, outside the graphs) ---------------------------------------
     def _reduce_eager_setup(self, bucket_bytes: int):
