@@ -50,7 +50,7 @@ WORKLOADS = {
 T = 4096
 CROP = (500, 4500)
 BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16
-TRAFFIC_FILE = "r01_hbm_traffic.json"
+TRAFFIC_FILE = "r02_hbm_traffic.json"
 KERNEL_DESCR = {
     "conv_fwd2_kernel": "conv_fwd2_kernel_128/_192 (bf16 implicit-GEMM tap-list conv, forward and data-grad launches)",
     "conv_stream_kernel": "conv_stream_kernel (bf16 single-tap conv, persistent 256x128 tiles)",
