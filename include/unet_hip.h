@@ -183,6 +183,29 @@ int unet_affine_act_bwd_apply_sum(int32_t dtype, const void* y, const void* dz, 
                                   const float* cb, const float* cc, void* dy, float* dy_sum_part, int32_t n,
                                   int32_t rows, int32_t c, void* stream);
 
+/* Norm + activation + squeeze-excite as one unit (models.py:801-839: the norm, nn.GELU and SqueezeExcitation1D of a
+ * ModernConvBlock; SE itself models.py:637-662).  z = act(a*y+b) * s[n][c], s = SE-MLP(mean_t act(a*y+b)):
+ *   unet_affine_pool            pool_part = partial sums over rows of act(a*y+b); nothing else is stored
+ *   unet_affine_act_scale_fwd   z = act(a*y+b) * s
+ *   unet_affine_act_se_bwd_reduce   ONE pass over (y, dz): p_part[k][n][part][c], k = 0..4:
+ *                               sum dz*act, sum dz*act', sum dz*act'*y, sum act', sum act'*y   (p_part: 5*n*parts*c floats)
+ *   unet_se_combine             on the part-reduced sums p[5][n][c]:  g1 = s*p1 + dpool*p3, g2 = s*p2 + dpool*p4
+ *                               (= sum_t g, sum_t g*y of unet_affine_act_bwd_reduce; p0 = d s goes through the SE MLP
+ *                               backward to give dpool first; dpool may be NULL)
+ *   unet_affine_act_se_bwd_apply    dy = ca*g + cb*y + cc with g = (dz*s + dpool)*act'(a*y+b), + column sums of dy */
+int unet_affine_pool(int32_t dtype, const void* y, const float* a, const float* b, int32_t act, float* pool_part,
+                     int32_t n, int32_t rows, int32_t c, void* stream);
+int unet_affine_act_scale_fwd(int32_t dtype, const void* y, const float* a, const float* b, int32_t act, const float* s,
+                              void* z, int32_t n, int32_t rows, int32_t c, void* stream);
+int unet_affine_act_se_bwd_reduce(int32_t dtype, const void* y, const void* dz, const float* a, const float* b,
+                                  int32_t act, float* p_part, int32_t n, int32_t rows, int32_t c, void* stream);
+int unet_se_combine(const float* p, const float* s, const float* dpool, float* g1, float* g2, int32_t n, int32_t c,
+                    void* stream);
+int unet_affine_act_se_bwd_apply(int32_t dtype, const void* y, const void* dz, const float* dpool, const float* s,
+                                 const float* a, const float* b, int32_t act, const float* ca, const float* cb,
+                                 const float* cc, void* dy, float* dy_sum_part, int32_t n, int32_t rows, int32_t c,
+                                 void* stream);
+
 /* out = x * s[n][c]  (SE excite, models.py:662);  bwd: dx = dout*s, ds_part = sum_t dout*x */
 int unet_scale_fwd(int32_t dtype, const void* x, const float* s, void* out, int32_t n, int32_t rows,
                    int32_t c, void* stream);

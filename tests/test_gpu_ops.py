@@ -266,3 +266,45 @@ def test_small_linear_group(dims):
         assert rel(m[0].grad, w.grad) < 1e-5
         if b is not None:
             assert rel(m[1].grad, b.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dtype,shape", [(torch.float32, (3, 200, 48)), (torch.float32, (2, 77, 20)),
+                                         (torch.bfloat16, (4, 1024, 256)), (torch.bfloat16, (2, 130, 64))])
+def test_batchnorm_act_se_node_matches_torch(dtype, shape):
+    """BatchNormActSEFn (norm + GELU + squeeze-excite as one node: pool-only pass, fused apply, five-sum backward)
+    against the same expression in fp64 torch autograd: models.py:801-839 (BatchNorm1d in training mode, nn.GELU,
+    SqueezeExcitation1D models.py:637-662).  fp32 <= 2e-5 / 2e-4 (output / gradients); bf16: the kernel reads bf16 y
+    and dz and stores bf16, the reference takes the same bf16-rounded inputs, so the bars are the bf16 store's."""
+    ops = _ops()
+    n, rows, c = shape
+    red = max(c // 4, 8)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    y = (torch.randn(n, rows, c, device="cuda", generator=g) * 1.5 + 0.3).to(dtype).requires_grad_(True)
+    gamma = (torch.rand(c, device="cuda", generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(c, device="cuda", generator=g) * 0.2).requires_grad_(True)
+    w0 = (torch.randn(red, c, device="cuda", generator=g) * 0.3).requires_grad_(True)
+    w2 = (torch.randn(c, red, device="cuda", generator=g) * 0.3).requires_grad_(True)
+    rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    dz = torch.randn(n, rows, c, device="cuda", generator=g).to(dtype)
+    z = ops.BatchNormActSEFn.apply(y, gamma, beta, rm, rv, 0.1, 1e-5, ops_act_id("gelu"), w0, w2)
+    z.backward(dz)
+
+    yd, gd, bd, w0d, w2d = (t.detach().double().requires_grad_(True) for t in (y, gamma, beta, w0, w2))
+    mean = yd.mean(dim=(0, 1))
+    var = yd.var(dim=(0, 1), unbiased=False)
+    act = F.gelu((yd - mean) / torch.sqrt(var + 1e-5) * gd + bd)
+    s = torch.sigmoid(F.gelu(act.mean(dim=1) @ w0d.t()) @ w2d.t())
+    zr = act * s[:, None, :]
+    zr.backward(dz.double())
+    to, tg = (2e-5, 2e-4) if dtype == torch.float32 else (6e-3, 2e-2)
+    assert rel(z, zr) < to
+    assert rel(y.grad, yd.grad) < tg
+    for mine, ref in ((gamma, gd), (beta, bd), (w0, w0d), (w2, w2d)):
+        assert rel(mine.grad, ref.grad) < tg
+    cnt = n * rows
+    assert rel(rm, 0.1 * mean) < 1e-5 and rel(rv, 0.9 + 0.1 * var * cnt / (cnt - 1)) < 1e-5
+
+
+def ops_act_id(name):
+    from unet_amd.model import ACT_IDS
+    return ACT_IDS[name]

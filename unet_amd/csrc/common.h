@@ -155,6 +155,19 @@ __device__ __forceinline__ float act_bwd(int act, float x) {
   }
 }
 
+// act(x) and act'(x) together (the GELU pair shares its erf / exp)
+__device__ __forceinline__ void act_both(int act, float x, float& f, float& d) {
+  if (act == UNET_ACT_GELU) {
+    float c, e;
+    gelu_cdf(x, c, e);
+    f = x * c;
+    d = fmaf(x * 0.3989422804014327f, e, c);
+  } else {
+    f = act_fwd(act, x);
+    d = act_bwd(act, x);
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -150,17 +150,20 @@ template <typename T, int V_, bool POOL> struct AffineActFwdOp : OpBase<T, V_> {
 };
 
 // ---- backward of the above ---------------------------------------------------------------------
-template <typename T, int V_, bool APPLY, bool BSUM = false> struct AffineActBwdOp : OpBase<T, V_> {
+// SC: dz is the gradient of z = act(a*y+b)*sc (the squeeze-excite gate folded in): g = (dz*sc + dpool) * act'
+template <typename T, int V_, bool APPLY, bool BSUM = false, bool SC = false> struct AffineActBwdOp : OpBase<T, V_> {
   static constexpr int NRED = APPLY ? (BSUM ? 1 : 0) : 2, NIN = 2;
+  const float* sc = nullptr;
   static constexpr int UNROLL = APPLY ? 4 : 2;   // the reduce pass at 4 rows crosses 128 VGPRs and loses a wave per SIMD (measured +10 %)
   const T* y; const T* dz; const float* dpool; const float* a; const float* b; int act;
   float* dysum;                               // apply with BSUM: per-part column sums of dy (the producing conv's bias gradient)
   float* g1; float* g2;                       // reduce
   const float* ca; const float* cb; const float* cc; T* dy;  // apply
-  struct State { float a[V_], b[V_], dp[V_], ca[V_], cb[V_], cc[V_]; };
+  struct State { float a[V_], b[V_], dp[V_], ca[V_], cb[V_], cc[V_], sc[SC ? V_ : 1]; };
   __device__ void init(State& s, int n, int c0, int c) const {
     const long long o = (long long)n * c + c0;
     this->ldc(a + o, s.a); this->ldc(b + o, s.b);
+    if constexpr (SC) this->ldc(sc + o, s.sc);
     if (dpool) this->ldc(dpool + o, s.dp);
     else {
 #pragma unroll
@@ -177,7 +180,8 @@ template <typename T, int V_, bool APPLY, bool BSUM = false> struct AffineActBwd
 #pragma unroll
     for (int i = 0; i < V_; ++i) {
       const float fy = in[0][i];
-      const float g = (in[1][i] + s.dp[i]) * act_bwd(act, s.a[i] * fy + s.b[i]);
+      const float dzi = SC ? fmaf(in[1][i], s.sc[SC ? i : 0], s.dp[i]) : in[1][i] + s.dp[i];
+      const float g = dzi * act_bwd(act, s.a[i] * fy + s.b[i]);
       if (APPLY) {
         out[i] = s.ca[i] * g + s.cb[i] * fy + s.cc[i];
         if (BSUM) acc[0][i] += out[i];
@@ -190,6 +194,89 @@ template <typename T, int V_, bool APPLY, bool BSUM = false> struct AffineActBwd
     else { this->stc(g1 + e, s[0]); this->stc(g2 + e, s[APPLY ? 0 : 1]); }
   }
 };
+
+// ---- norm + activation + squeeze-excite as one unit (models.py:801-839: norm, GELU, SE) -------------------------
+// z = act(a*y+b) * s[n][c] with s = SE-MLP(mean_l act(a*y+b)): the gate needs the whole window first, so forward is a
+// pool-only pass (1 read, nothing stored) and a fused pass (1 read, 1 write) -- the unscaled activation never exists
+// in HBM (norm+act+pool R/W followed by scale R/W: 4 touches -> 3).
+template <typename T, int V_> struct AffinePoolOp : OpBase<T, V_> {
+  static constexpr int NRED = 1, NIN = 1;
+  const T* y; const float* a; const float* b; float* pool; int act;
+  struct State { float a[V_], b[V_]; };
+  __device__ void init(State& s, int n, int c0, int c) const {
+    this->ldc(a + (long long)n * c + c0, s.a); this->ldc(b + (long long)n * c + c0, s.b);
+  }
+  __device__ void ld(long long e, float (&in)[1][V_]) const { VecIO<T, V_>::load(y + e, in[0]); }
+  __device__ void row(State& s, long long, const float (&in)[1][V_], float (&acc)[1][V_]) const {
+#pragma unroll
+    for (int i = 0; i < V_; ++i) acc[0][i] += act_fwd(act, s.a[i] * in[0][i] + s.b[i]);
+  }
+  __device__ void write_part(long long e, const float (&s)[1][V_]) const { this->stc(pool + e, s[0]); }
+};
+template <typename T, int V_> struct AffineActScaleFwdOp : OpBase<T, V_> {
+  static constexpr int NRED = 0, NIN = 1;
+  const T* y; T* z; const float* a; const float* b; const float* sc; int act;
+  struct State { float a[V_], b[V_], sc[V_]; };
+  __device__ void init(State& s, int n, int c0, int c) const {
+    const long long o = (long long)n * c + c0;
+    this->ldc(a + o, s.a); this->ldc(b + o, s.b); this->ldc(sc + o, s.sc);
+  }
+  __device__ void ld(long long e, float (&in)[1][V_]) const { VecIO<T, V_>::load(y + e, in[0]); }
+  __device__ void row(State& s, long long e, const float (&in)[1][V_], float (&)[1][V_]) const {
+    float f[V_];
+#pragma unroll
+    for (int i = 0; i < V_; ++i) f[i] = act_fwd(act, s.a[i] * in[0][i] + s.b[i]) * s.sc[i];
+    VecIO<T, V_>::store(z + e, f);
+  }
+  __device__ void write_part(long long, const float (&)[1][V_]) const {}
+};
+// Backward, given dz = d loss / d z.  With u = a*y+b:  d s = sum_l dz*act(u), and the two sums the norm backward
+// needs, sum_l g and sum_l g*y with g = (dz*s + dpool)*act'(u), are LINEAR in the per-(window, channel) constants s
+// and dpool (dpool = the pool's gradient, known only after d s went through the SE MLP backward).  So ONE pass over
+// (y, dz) accumulates five sums per (window, channel),
+//   P0 = sum dz*act(u)   P1 = sum dz*act'(u)   P2 = sum dz*act'(u)*y   P3 = sum act'(u)   P4 = sum act'(u)*y,
+// and  sum g = s*P1 + dpool*P3,  sum g*y = s*P2 + dpool*P4  are formed on [N, C] afterwards (se_combine_kernel).
+// Replaces the SE-excite backward pass (3 touches) and the two-sum reduction pass (2 touches) by 2 touches.
+template <typename T, int V_> struct AffineActSEBwdReduceOp : OpBase<T, V_> {
+  static constexpr int NRED = 5, NIN = 2;
+  static constexpr int UNROLL = 2;
+  const T* y; const T* dz; const float* a; const float* b; float* p; long long pstride; int act;
+  struct State { float a[V_], b[V_]; };
+  __device__ void init(State& s, int n, int c0, int c) const {
+    this->ldc(a + (long long)n * c + c0, s.a); this->ldc(b + (long long)n * c + c0, s.b);
+  }
+  __device__ void ld(long long e, float (&in)[2][V_]) const {
+    VecIO<T, V_>::load(y + e, in[0]);
+    VecIO<T, V_>::load(dz + e, in[1]);
+  }
+  __device__ void row(State& s, long long, const float (&in)[2][V_], float (&acc)[5][V_]) const {
+#pragma unroll
+    for (int i = 0; i < V_; ++i) {
+      const float fy = in[0][i], d = in[1][i];
+      float f, fp;
+      act_both(act, s.a[i] * fy + s.b[i], f, fp);
+      const float dfp = d * fp;
+      acc[0][i] += d * f;
+      acc[1][i] += dfp;
+      acc[2][i] += dfp * fy;
+      acc[3][i] += fp;
+      acc[4][i] += fp * fy;
+    }
+  }
+  __device__ void write_part(long long e, const float (&s)[5][V_]) const {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) this->stc(p + k * pstride + e, s[k]);
+  }
+};
+
+__global__ void se_combine_kernel(const float* __restrict__ p, long long nc, const float* __restrict__ s,
+                                  const float* __restrict__ dpool, float* __restrict__ g1, float* __restrict__ g2) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nc) return;
+  const float sv = s[i], dp = dpool ? dpool[i] : 0.f;
+  g1[i] = fmaf(sv, p[nc + i], dp * p[3 * nc + i]);
+  g2[i] = fmaf(sv, p[2 * nc + i], dp * p[4 * nc + i]);
+}
 
 // ---- out = x*s ;  dx = dout*s, ds = sum dout*x ----------------------------------------------------
 template <typename T, int V_> struct ScaleFwdOp : OpBase<T, V_> {
@@ -858,6 +945,69 @@ extern "C" int unet_affine_act_bwd_apply_sum(int32_t dtype, const void* y, const
     AffineActBwdOp<T, V, true, true> op; op.y = (const T*)y; op.dz = (const T*)dz; op.dpool = dpool; op.a = a; op.b = b;
     op.act = act; op.g1 = op.g2 = nullptr; op.ca = ca; op.cb = cb; op.cc = cc; op.dy = (T*)dy; op.dysum = dy_sum_part;
     return launch_rows(op, n, rows, c, st, "affine_act_bwd_apply_sum");
+  });
+  return 0;
+}
+
+extern "C" int unet_affine_pool(int32_t dtype, const void* y, const float* a, const float* b, int32_t act,
+                                float* pool_part, int32_t n, int32_t rows, int32_t c, void* stream) {
+  if (check_dims(n, rows, c, "affine_pool")) return -1;
+  UNET_REQUIRE(y && a && b && pool_part, "affine_pool: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH_ROWS(dtype, c, PL(y), {
+    AffinePoolOp<T, V> op; op.y = (const T*)y; op.a = a; op.b = b; op.pool = pool_part; op.act = act;
+    return launch_rows(op, n, rows, c, st, "affine_pool");
+  });
+  return 0;
+}
+
+extern "C" int unet_affine_act_scale_fwd(int32_t dtype, const void* y, const float* a, const float* b, int32_t act,
+                                         const float* s, void* z, int32_t n, int32_t rows, int32_t c, void* stream) {
+  if (check_dims(n, rows, c, "affine_act_scale_fwd")) return -1;
+  UNET_REQUIRE(y && a && b && s && z, "affine_act_scale_fwd: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH_ROWS(dtype, c, PL(y, z), {
+    AffineActScaleFwdOp<T, V> op; op.y = (const T*)y; op.z = (T*)z; op.a = a; op.b = b; op.sc = s; op.act = act;
+    return launch_rows(op, n, rows, c, st, "affine_act_scale_fwd");
+  });
+  return 0;
+}
+
+extern "C" int unet_affine_act_se_bwd_reduce(int32_t dtype, const void* y, const void* dz, const float* a, const float* b,
+                                             int32_t act, float* p_part, int32_t n, int32_t rows, int32_t c, void* stream) {
+  if (check_dims(n, rows, c, "affine_act_se_bwd_reduce")) return -1;
+  UNET_REQUIRE(y && dz && a && b && p_part, "affine_act_se_bwd_reduce: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH_ROWS(dtype, c, PL(y, dz), {
+    AffineActSEBwdReduceOp<T, V> op; op.y = (const T*)y; op.dz = (const T*)dz; op.a = a; op.b = b; op.act = act;
+    op.p = p_part; op.pstride = (long long)n * cdiv(rows, rows_per_part(rows)) * c;
+    return launch_rows(op, n, rows, c, st, "affine_act_se_bwd_reduce");
+  });
+  return 0;
+}
+
+extern "C" int unet_se_combine(const float* p, const float* s, const float* dpool, float* g1, float* g2, int32_t n,
+                               int32_t c, void* stream) {
+  UNET_REQUIRE(p && s && g1 && g2 && n > 0 && c > 0, "se_combine: bad arguments");
+  const long long nc = (long long)n * c;
+  hipLaunchKernelGGL(se_combine_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p,
+                     nc, s, dpool, g1, g2);
+  UNET_LAUNCH_CHECK("se_combine");
+  return 0;
+}
+
+extern "C" int unet_affine_act_se_bwd_apply(int32_t dtype, const void* y, const void* dz, const float* dpool,
+                                            const float* s, const float* a, const float* b, int32_t act, const float* ca,
+                                            const float* cb, const float* cc, void* dy, float* dy_sum_part, int32_t n,
+                                            int32_t rows, int32_t c, void* stream) {
+  if (check_dims(n, rows, c, "affine_act_se_bwd_apply")) return -1;
+  UNET_REQUIRE(y && dz && s && a && b && ca && cb && cc && dy && dy_sum_part, "affine_act_se_bwd_apply: null pointer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH_ROWS(dtype, c, PL(y, dz, dy), {
+    AffineActBwdOp<T, V, true, true, true> op; op.y = (const T*)y; op.dz = (const T*)dz; op.dpool = dpool; op.sc = s;
+    op.a = a; op.b = b; op.act = act; op.g1 = op.g2 = nullptr; op.ca = ca; op.cb = cb; op.cc = cc; op.dy = (T*)dy;
+    op.dysum = dy_sum_part;
+    return launch_rows(op, n, rows, c, st, "affine_act_se_bwd_apply");
   });
   return 0;
 }

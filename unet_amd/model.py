@@ -19,6 +19,7 @@ Out-of-scope constructor options raise ``NotImplementedError`` (never a silent f
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Tuple, Union
 
 import torch
@@ -76,7 +77,19 @@ def _make_norm(norm_type: str, c: int) -> nn.Module:
     raise ValueError(f"Unknown norm_type: {norm_type}. Available: batch, instance, group, layer, rms, none")
 
 
-def _norm_act(y: Tensor, norm: nn.Module, act_id: int, want_pool: bool):
+FUSE_SE = os.environ.get("UNET_FUSE_SE", "1") != "0"    # 0: the unfused kernels (A/B measurements)
+
+
+def _norm_act_se(y: Tensor, norm: nn.Module, act_id: int, se: "SqueezeExcitation1D") -> Tensor:
+    """SE(act(norm(y))) for y in NLC (models.py:801-839).  Training-mode BatchNorm -- the production path -- is one
+    fused autograd node; every other norm takes the general kernels followed by the SE scale."""
+    if FUSE_SE and isinstance(norm, nn.BatchNorm1d) and (norm.training or norm.running_mean is None):
+        return _norm_act(y, norm, act_id, False, se=se)
+    z, pool = _norm_act(y, norm, act_id, True)
+    return ops.ScaleFn.apply(z, se.gate_from_pool(pool, z.shape[1]))
+
+
+def _norm_act(y: Tensor, norm: nn.Module, act_id: int, want_pool: bool, se=None):
     """z = act(norm(y)) (+ per-(window, channel) sum of z over rows) for y in NLC."""
     n, rows, c = y.shape
     if isinstance(norm, nn.Identity):
@@ -96,6 +109,9 @@ def _norm_act(y: Tensor, norm: nn.Module, act_id: int, want_pool: bool):
             rv = norm.running_var if track else None
             if rm is not None and (rm.dtype != torch.float32 or not rm.is_contiguous()):
                 raise TypeError("BatchNorm running buffers must be contiguous fp32")
+            if se is not None:
+                return ops.BatchNormActSEFn.apply(y, norm.weight, norm.bias, rm, rv, float(mom or 0.0), float(norm.eps),
+                                                  act_id, se.fc[0].weight, se.fc[2].weight)
             return ops.BatchNormActFn.apply(y, norm.weight, norm.bias, rm, rv, float(mom or 0.0), float(norm.eps),
                                             act_id, want_pool)
         else:
@@ -436,9 +452,7 @@ class SqueezeExcitation1D(nn.Module):
     def gate_from_pool(self, pool_sum: Tensor, rows: int) -> Tensor:
         """sigmoid(W2 gelu(W0 (pool_sum / rows))): two launches (models.py:660-661; the mean's 1/rows is the first
         map's scale)."""
-        (h,) = ops.small_linear_group(pool_sum, ((self.fc[0].weight, None, "gelu", 1.0 / rows),))
-        (s,) = ops.small_linear_group(h, ((self.fc[2].weight, None, "sigmoid", 1.0),))
-        return s
+        return ops.se_gate(pool_sum, self.fc[0].weight, self.fc[2].weight, rows)
 
     def forward(self, x: Tensor) -> Tensor:
         xn = _to_nlc(x)
@@ -520,8 +534,7 @@ class ModernConvBlock(nn.Module):
     def forward_nlc(self, x1: Tensor, emb: Optional[Tensor], x2: Optional[Tensor] = None) -> Tensor:
         y = self.conv[0].forward_nlc(x1, x2)
         if self.use_se:
-            z, pool = _norm_act(y, self.conv[1], ACT_IDS["gelu"], True)
-            z = ops.ScaleFn.apply(z, self.conv[3].gate_from_pool(pool, z.shape[1]))
+            z = _norm_act_se(y, self.conv[1], ACT_IDS["gelu"], self.conv[3])
         else:
             z = _norm_act(y, self.conv[1], ACT_IDS["gelu"], False)
         z = _dropout1d_nlc(z, self.dropout_p, self.training)

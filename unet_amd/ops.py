@@ -652,6 +652,90 @@ class BatchNormActFn(torch.autograd.Function):
         return dy, dgamma, dbeta, None, None, None, None, None, None
 
 
+def se_gate(pool_sum: Tensor, w0: Tensor, w2: Tensor, rows: int) -> Tensor:
+    """sigmoid(W2 gelu(W0 (pool_sum / rows))): the SE excitation MLP (models.py:660-661), two launches; the mean's
+    1/rows is the first map's scale."""
+    (h,) = small_linear_group(pool_sum, ((w0, None, "gelu", 1.0 / rows),))
+    (s,) = small_linear_group(h, ((w2, None, "sigmoid", 1.0),))
+    return s
+
+
+class BatchNormActSEFn(torch.autograd.Function):
+    """z = act(BatchNorm1d_train(y)) * s,  s = SE-MLP(mean over rows of act(BatchNorm(y)))  -- the norm, GELU and
+    SqueezeExcitation1D of a ModernConvBlock (models.py:801-839, 637-662) as one autograd node.
+
+    Forward: statistics pass, pool-only pass, MLP, fused apply pass; the unscaled activation is never stored.
+    Backward: one five-sum pass over (y, dz) (csrc/stream.hip, AffineActSEBwdReduceOp), the MLP backward on [N, C],
+    a combine on [N, C], BatchNorm's finalisation, one apply pass: 2 + 3 activation touches instead of the 3 + 2 + 3
+    of SE-excite backward + norm reduction + norm apply."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum: float, eps: float, act_id: int, w0, w2):
+        lib = _lib.load()
+        _need_cuda(y)
+        y = y.contiguous()
+        n, rows, c = y.shape
+        dt, st = _dt(y), _stream()
+        s1p, s2p = _part_buf(y, 2)
+        check(lib.unet_rowstats(dt, _p(y), _p(s1p), _p(s2p), n, rows, c, st), "unet_rowstats")
+        coef = torch.empty((4, n, c), dtype=torch.float32, device=y.device)
+        mean, rstd, a, b = coef[0], coef[1], coef[2], coef[3]
+        gf = _f32c(gamma) if gamma is not None else None
+        bf = _f32c(beta) if beta is not None else None
+        check(lib.unet_bn_finalize_fwd(_p(s1p), _p(s2p), n, s1p.shape[1], c, rows, eps, _p(gf), _p(bf),
+                                       _p(running_mean), _p(running_var), momentum, _p(mean), _p(rstd), _p(a), _p(b),
+                                       st), "unet_bn_finalize_fwd")
+        check(lib.unet_affine_pool(dt, _p(y), _p(a), _p(b), act_id, _p(s1p), n, rows, c, st), "unet_affine_pool")
+        pool = sum_parts(s1p)
+        # the SE MLP (models.py:660-661) by raw launches; its backward runs in the middle of this node's backward
+        w0f, w2f = _f32c(w0), _f32c(w2)
+        gelu, sig = _lib.SMALL_ACT["gelu"], _lib.SMALL_ACT["sigmoid"]
+        (h,), (hpre,) = _small_fwd(pool, (gelu,), (1.0 / rows,), [w0f], [None])
+        (sd,), _ = _small_fwd(h, (sig,), (1.0,), [w2f], [None])
+        z = torch.empty_like(y)
+        check(lib.unet_affine_act_scale_fwd(dt, _p(y), _p(a), _p(b), act_id, _p(sd), _p(z), n, rows, c, st),
+              "unet_affine_act_scale_fwd")
+        ctx.act_id = act_id
+        ctx.has_affine = gamma is not None
+        ctx.gdtype = gamma.dtype if gamma is not None else torch.float32
+        ctx.wdtypes = (w0.dtype, w2.dtype)
+        ctx.save_for_backward(y, coef, gf, sd, pool, h, hpre, w0f, w2f)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        y, coef, gf, sd, pool, h, hpre, w0f, w2f = ctx.saved_tensors
+        mean, rstd, a, b = coef[0], coef[1], coef[2], coef[3]
+        n, rows, c = y.shape
+        dt, st = _dt(y), _stream()
+        dz = dz.contiguous()
+        np_ = parts(rows)
+        pp = torch.empty((5, n, np_, c), dtype=torch.float32, device=y.device)
+        check(lib.unet_affine_act_se_bwd_reduce(dt, _p(y), _p(dz), _p(a), _p(b), ctx.act_id, _p(pp), n, rows, c, st),
+              "unet_affine_act_se_bwd_reduce")
+        ps = sum_parts(pp.view(5 * n, np_, c))                       # [5*N, C] = P0..P4 of [N, C]
+        gelu, sig = _lib.SMALL_ACT["gelu"], _lib.SMALL_ACT["sigmoid"]
+        dh, (dw2,), _ = _small_bwd(h, (sig,), (1.0,), [w2f], [sd], [None], [ps[:n]], True, [True], [False])
+        dpool, (dw0,), _ = _small_bwd(pool, (gelu,), (1.0 / rows,), [w0f], [h], [hpre], [dh], True, [True], [False])
+        g12 = torch.empty((2, n, 1, c), dtype=torch.float32, device=y.device)
+        check(lib.unet_se_combine(_p(ps), _p(sd), _p(dpool), _p(g12[0]), _p(g12[1]), n, c, st), "unet_se_combine")
+        cf = torch.empty((3, n, c), dtype=torch.float32, device=y.device)
+        dgb = torch.empty((2, c), dtype=torch.float32, device=y.device)
+        check(lib.unet_bn_finalize_bwd(_p(g12[0]), _p(g12[1]), n, 1, c, rows, _p(mean), _p(rstd), _p(gf),
+                                       _p(cf[0]), _p(cf[1]), _p(cf[2]), _p(dgb[0]), _p(dgb[1]), st),
+              "unet_bn_finalize_bwd")
+        dy = torch.empty_like(y)
+        bsum = pp[0]                                                 # consumed by sum_parts: free for the column sums
+        check(lib.unet_affine_act_se_bwd_apply(dt, _p(y), _p(dz), _p(dpool), _p(sd), _p(a), _p(b), ctx.act_id, _p(cf[0]),
+                                               _p(cf[1]), _p(cf[2]), _p(dy), _p(bsum), n, rows, c, st),
+              "unet_affine_act_se_bwd_apply")
+        _offer_colsum(dy, bsum)
+        dgamma = dgb[0].to(ctx.gdtype) if ctx.has_affine else None
+        dbeta = dgb[1].to(ctx.gdtype) if ctx.has_affine else None
+        return dy, dgamma, dbeta, None, None, None, None, None, dw0.to(ctx.wdtypes[0]), dw2.to(ctx.wdtypes[1])
+
+
 def activation(x: Tensor, act_id: int) -> Tensor:
     return AffineActFn.apply(x, None, None, None, act_id, False)
 
@@ -802,6 +886,70 @@ class FilmFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # per-window vector algebra: groups of small Linear layers (csrc/small.hip)
 # ---------------------------------------------------------------------------------------------
+def _small_fwd(xf: Tensor, acts, scales, ws, bs):
+    """Launch of unet_small_linear_fwd: xf [N, I] fp32, ws / bs fp32 (bias may be None) -> (ys, pres)."""
+    lib = _lib.load()
+    np_ = len(acts)
+    n, n_in = xf.shape
+    ys, pres = [], []
+    splits = int(lib.unet_small_linear_splits(n_in))
+    parts_ = []          # split-K partial sums of wide maps, consumed by the finishing launch
+    probs = (_lib.SmallLinear * np_)()
+    for i in range(np_):
+        n_out = ws[i].shape[0]
+        if ws[i].shape[1] != n_in:
+            raise ValueError(f"weight {tuple(ws[i].shape)} does not take {n_in} inputs")
+        y = torch.empty((n, n_out), dtype=torch.float32, device=xf.device)
+        pre = torch.empty_like(y) if acts[i] == _lib.SMALL_ACT["gelu"] else None
+        q = probs[i]
+        q.x, q.w, q.b, q.y, q.pre = xf.data_ptr(), ws[i].data_ptr(), (bs[i].data_ptr() if bs[i] is not None else None), \
+            y.data_ptr(), (pre.data_ptr() if pre is not None else None)
+        q.n_in, q.n_out, q.act, q.scale = n_in, n_out, acts[i], float(scales[i])
+        if splits > 1:
+            parts_.append(torch.empty((splits, n, n_out), dtype=torch.float32, device=xf.device))
+            q.part = parts_[-1].data_ptr()
+        ys.append(y)
+        pres.append(pre)
+    check(lib.unet_small_linear_fwd(probs, np_, n, _stream()), "unet_small_linear_fwd")
+    return ys, pres
+
+
+def _small_bwd(xf: Tensor, acts, scales, ws, ys, pres, dys, need_x: bool, need_w, need_b):
+    """Launch of unet_small_linear_bwd -> (dx | None, dws, dbs), all fp32."""
+    lib = _lib.load()
+    np_ = len(acts)
+    n, n_in = xf.shape
+    tiles = [int(lib.unet_small_linear_tiles(w.shape[0])) for w in ws]
+    dx_part = torch.empty((sum(tiles), n * n_in), dtype=torch.float32, device=xf.device) if need_x else None
+    probs = (_lib.SmallLinear * np_)()
+    keep, dws, dbs, slot = [], [], [], 0
+    for i in range(np_):
+        n_out = ws[i].shape[0]
+        dy = dys[i]
+        dy = torch.zeros((n, n_out), dtype=torch.float32, device=xf.device) if dy is None else _f32c(dy)
+        pre = pres[i]
+        dw = torch.empty_like(ws[i]) if need_w[i] else None
+        db = torch.empty(n_out, dtype=torch.float32, device=xf.device) if need_b[i] else None
+        q = probs[i]
+        q.x, q.w, q.b, q.y, q.pre = xf.data_ptr(), ws[i].data_ptr(), None, ys[i].data_ptr(), (pre.data_ptr() if pre is not None else None)
+        q.n_in, q.n_out, q.act, q.scale = n_in, n_out, acts[i], float(scales[i])
+        q.dy = dy.data_ptr()
+        q.dw = dw.data_ptr() if dw is not None else None
+        q.db = db.data_ptr() if db is not None else None
+        q.dx_part = dx_part.data_ptr() if need_x else None
+        q.dx_slot0 = slot
+        slot += tiles[i]
+        keep.append(dy)
+        dws.append(dw)
+        dbs.append(db)
+    check(lib.unet_small_linear_bwd(probs, np_, n, _stream()), "unet_small_linear_bwd")
+    dx = None
+    if need_x:
+        dx = torch.empty((n, n_in), dtype=torch.float32, device=xf.device)
+        check(lib.unet_reduce_rows(_p(dx_part), dx_part.shape[0], n * n_in, _p(dx), _stream()), "unet_reduce_rows")
+    return dx, dws, dbs
+
+
 class SmallLinearGroupFn(torch.autograd.Function):
     """y_p = act_p(scale_p * (x W_p^T + b_p)) for up to 4 Linear maps of ONE input x [N, I]: FiLM's k_proj / v_proj /
     gate on the conditioning embedding (models.py:506-509) and the SE excitation MLP (models.py:660-661).  One launch
@@ -809,35 +957,14 @@ class SmallLinearGroupFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, acts: Tuple[int, ...], scales: Tuple[float, ...], *wb):
-        lib = _lib.load()
         _need_cuda(x)
         np_ = len(acts)
         if np_ < 1 or np_ > _lib.SMALL_MAX or len(wb) != 2 * np_:
             raise ValueError("1..4 (weight, bias) pairs")
         xf = _f32c(x)
-        n, n_in = xf.shape
         ws = [_f32c(wb[2 * i]) for i in range(np_)]
         bs = [(_f32c(wb[2 * i + 1]) if wb[2 * i + 1] is not None else None) for i in range(np_)]
-        ys, pres = [], []
-        splits = int(lib.unet_small_linear_splits(n_in))
-        parts = []          # split-K partial sums of wide maps, consumed by the finishing launch
-        probs = (_lib.SmallLinear * np_)()
-        for i in range(np_):
-            n_out = ws[i].shape[0]
-            if ws[i].shape[1] != n_in:
-                raise ValueError(f"weight {tuple(ws[i].shape)} does not take {n_in} inputs")
-            y = torch.empty((n, n_out), dtype=torch.float32, device=xf.device)
-            pre = torch.empty_like(y) if acts[i] == _lib.SMALL_ACT["gelu"] else None
-            q = probs[i]
-            q.x, q.w, q.b, q.y, q.pre = xf.data_ptr(), ws[i].data_ptr(), (bs[i].data_ptr() if bs[i] is not None else None), \
-                y.data_ptr(), (pre.data_ptr() if pre is not None else None)
-            q.n_in, q.n_out, q.act, q.scale = n_in, n_out, acts[i], float(scales[i])
-            if splits > 1:
-                parts.append(torch.empty((splits, n, n_out), dtype=torch.float32, device=xf.device))
-                q.part = parts[-1].data_ptr()
-            ys.append(y)
-            pres.append(pre)
-        check(lib.unet_small_linear_fwd(probs, np_, n, _stream()), "unet_small_linear_fwd")
+        ys, pres = _small_fwd(xf, acts, scales, ws, bs)
         ctx.acts, ctx.scales, ctx.np = acts, scales, np_
         ctx.has_b = [b is not None for b in bs]
         ctx.has_pre = [p is not None for p in pres]
@@ -847,43 +974,15 @@ class SmallLinearGroupFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *dys):
-        lib = _lib.load()
         np_ = ctx.np
         saved = ctx.saved_tensors
         xf, ws, ys = saved[0], saved[1:1 + np_], saved[1 + np_:1 + 2 * np_]
         pres_it = iter(saved[1 + 2 * np_:])
-        n, n_in = xf.shape
-        need_x = ctx.needs_input_grad[0]
-        tiles = [int(lib.unet_small_linear_tiles(w.shape[0])) for w in ws]
-        dx_part = torch.empty((sum(tiles), n * n_in), dtype=torch.float32, device=xf.device) if need_x else None
-        probs = (_lib.SmallLinear * np_)()
-        keep, dws, dbs, slot = [], [], [], 0
-        for i in range(np_):
-            n_out = ws[i].shape[0]
-            dy = dys[i]
-            dy = torch.zeros((n, n_out), dtype=torch.float32, device=xf.device) if dy is None else _f32c(dy)
-            pre = next(pres_it) if ctx.has_pre[i] else None
-            dw = torch.empty_like(ws[i]) if ctx.needs_input_grad[3 + 2 * i] else None
-            db = torch.empty(n_out, dtype=torch.float32, device=xf.device) if (ctx.has_b[i] and ctx.needs_input_grad[4 + 2 * i]) else None
-            q = probs[i]
-            q.x, q.w, q.b, q.y, q.pre = xf.data_ptr(), ws[i].data_ptr(), None, ys[i].data_ptr(), (pre.data_ptr() if pre is not None else None)
-            q.n_in, q.n_out, q.act, q.scale = n_in, n_out, ctx.acts[i], float(ctx.scales[i])
-            q.dy = dy.data_ptr()
-            q.dw = dw.data_ptr() if dw is not None else None
-            q.db = db.data_ptr() if db is not None else None
-            q.dx_part = dx_part.data_ptr() if need_x else None
-            q.dx_slot0 = slot
-            slot += tiles[i]
-            keep.append(dy)
-            dws.append(dw)
-            dbs.append(db)
-        check(lib.unet_small_linear_bwd(probs, np_, n, _stream()), "unet_small_linear_bwd")
-        dx = None
-        if need_x:
-            dx = torch.empty((n, n_in), dtype=torch.float32, device=xf.device)
-            check(lib.unet_reduce_rows(_p(dx_part), dx_part.shape[0], n * n_in, _p(dx), _stream()), "unet_reduce_rows")
-            dx = dx.to(ctx.dtypes[0])
-        out = [dx, None, None]
+        pres = [next(pres_it) if ctx.has_pre[i] else None for i in range(np_)]
+        need_w = [ctx.needs_input_grad[3 + 2 * i] for i in range(np_)]
+        need_b = [ctx.has_b[i] and ctx.needs_input_grad[4 + 2 * i] for i in range(np_)]
+        dx, dws, dbs = _small_bwd(xf, ctx.acts, ctx.scales, ws, ys, pres, dys, ctx.needs_input_grad[0], need_w, need_b)
+        out = [dx.to(ctx.dtypes[0]) if dx is not None else None, None, None]
         for i in range(np_):
             wd, bd = ctx.dtypes[1 + 2 * i], ctx.dtypes[2 + 2 * i]
             out.append(dws[i].to(wd) if dws[i] is not None else None)
