@@ -256,7 +256,7 @@ int unet_merge_taps_bwd(const float* const* w_branch_host, const float* sw, int3
  *         16-output tile; the caller adds the slots (unet_reduce_rows) -- unet_small_linear_tiles(n_out) per problem.
  *         dw / db / dx_part nullable.
  * ---------------------------------------------------------------------------------- */
-#define UNET_SMALL_MAX 4
+#define UNET_SMALL_MAX 32
 enum { UNET_SMALL_NONE = 0, UNET_SMALL_GELU = 1, UNET_SMALL_SIGMOID = 2 };
 typedef struct UnetSmallLinear {
   const float* x; const float* w; const float* b;

@@ -143,7 +143,8 @@ def test_gradient_checkpointing_matches_reference(name):
 
 def test_gradient_checkpointing_bf16_same_as_plain():
     """bf16 kernels: the checkpointed step recomputes the same kernels on the same inputs, so loss and gradients
-    equal the plain step's bit for bit."""
+    equal the plain step's bit for bit -- except the embedding's gradient: the plain step sums the FiLM projections'
+    input gradients of all blocks in one launch, the checkpointed step block by block (fp32 summation order)."""
     z, info = _load("B_modern_add_bn_gelu")
     ob, tgt, ids = (torch.from_numpy(z[k]).cuda() for k in ("ob", "target", "odor_ids"))
     grads = []
@@ -157,4 +158,7 @@ def test_gradient_checkpointing_bf16_same_as_plain():
         grads.append((loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
     assert grads[0][0] == grads[1][0]
     for k, g in grads[0][1].items():
+        if k == "embed.weight":
+            assert rel(g, grads[1][1][k]) < 1e-6, k
+            continue
         assert torch.equal(g, grads[1][1][k]), k

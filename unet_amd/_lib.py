@@ -41,7 +41,7 @@ class SmallLinear(C.Structure):
                 ("dx_slot0", C.c_int32)]
 
 
-SMALL_MAX = 4
+SMALL_MAX = 32
 SMALL_ACT = {"none": 0, "gelu": 1, "sigmoid": 2}
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float

@@ -77,6 +77,7 @@ def _make_norm(norm_type: str, c: int) -> nn.Module:
     raise ValueError(f"Unknown norm_type: {norm_type}. Available: batch, instance, group, layer, rms, none")
 
 
+HOIST_FILM = os.environ.get("UNET_HOIST_FILM", "1") != "0"   # 0: per-block FiLM projections (A/B measurements)
 FUSE_SE = os.environ.get("UNET_FUSE_SE", "1") != "0"    # 0: the unfused kernels (A/B measurements)
 
 
@@ -379,14 +380,23 @@ class FiLM(nn.Module):
         elif cond_mode != "none":
             raise ValueError(f"Unknown cond_mode: {cond_mode}. Supported: 'none', 'cross_attn_gated'")
 
+    def emb_maps(self):
+        """k_proj (with the C^-1/2 of models.py:514 folded in), v_proj and the sigmoid gate as small-linear maps."""
+        gate = self.gate[0]
+        return ((self.k_proj.weight, self.k_proj.bias, "none", self.scale_factor),
+                (self.v_proj.weight, self.v_proj.bias, "none", 1.0),
+                (gate.weight, gate.bias, "sigmoid", 1.0))
+
+    _pre = None     # (emb, kk, v, g) set by CondUNet1D.forward: the projections of EVERY block's FiLM in one launch
+
     def forward_nlc(self, x: Tensor, emb: Optional[Tensor]) -> Tensor:
         if self.cond_mode == "none" or emb is None:
             return x
-        # k_proj (with the C^-1/2 of models.py:514 folded in), v_proj and the sigmoid gate: one launch for the three
-        gate = self.gate[0]
-        kk, v, g = ops.small_linear_group(emb, ((self.k_proj.weight, self.k_proj.bias, "none", self.scale_factor),
-                                                (self.v_proj.weight, self.v_proj.bias, "none", 1.0),
-                                                (gate.weight, gate.bias, "sigmoid", 1.0)))
+        pre = self._pre
+        if pre is not None and pre[0] is emb:
+            kk, v, g = pre[1:]
+        else:                                           # stand-alone use: one launch for this module's three maps
+            kk, v, g = ops.small_linear_group(emb, self.emb_maps())
         return ops.FilmFn.apply(x, self.q_proj.weight.permute(2, 0, 1), self.q_proj.bias,
                                 self.out_proj.weight.permute(2, 0, 1), self.out_proj.bias, kk, v, g)
 
@@ -999,6 +1009,24 @@ class CondUNet1D(nn.Module):
         else:
             emb = None
 
+        # The FiLM projections depend on the embedding alone: all blocks' k / v / gate maps run as ONE launch here
+        # (and one backward launch after the last block's backward) instead of one per block on the critical path.
+        # Not under gradient checkpointing, whose recomputation must replay each block's own launches.
+        films = []
+        if HOIST_FILM and emb is not None and not (self.gradient_checkpointing and self.training):
+            blocks = [self.inc, *self.encoders, *[getattr(d, "block", None) for d in self.decoders]]
+            films = [b.film for b in blocks if isinstance(getattr(b, "film", None), FiLM) and b.film.cond_mode != "none"]
+            if len(films) > 1:
+                proj = ops.small_linear_group(emb, [m for f in films for m in f.emb_maps()])
+                for i, f in enumerate(films):
+                    f._pre = (emb, *proj[3 * i:3 * i + 3])
+        try:
+            return self._forward_blocks(ob, raw_input, x0, emb, io_dtype, return_bottleneck, return_bottleneck_temporal)
+        finally:
+            for f in films:
+                f._pre = None
+
+    def _forward_blocks(self, ob, raw_input, x0, emb, io_dtype, return_bottleneck, return_bottleneck_temporal):
         def run(block, *a):
             if self.gradient_checkpointing and self.training:
                 from torch.utils.checkpoint import checkpoint

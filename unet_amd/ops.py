@@ -960,7 +960,7 @@ class SmallLinearGroupFn(torch.autograd.Function):
         _need_cuda(x)
         np_ = len(acts)
         if np_ < 1 or np_ > _lib.SMALL_MAX or len(wb) != 2 * np_:
-            raise ValueError("1..4 (weight, bias) pairs")
+            raise ValueError(f"1..{_lib.SMALL_MAX} (weight, bias) pairs")
         xf = _f32c(x)
         ws = [_f32c(wb[2 * i]) for i in range(np_)]
         bs = [(_f32c(wb[2 * i + 1]) if wb[2 * i + 1] is not None else None) for i in range(np_)]
@@ -992,12 +992,16 @@ class SmallLinearGroupFn(torch.autograd.Function):
 
 def small_linear_group(x: Tensor, maps) -> Tuple[Tensor, ...]:
     """maps: sequence of (weight [O, I], bias [O] | None, activation "none" | "gelu" | "sigmoid", scale)."""
-    acts = tuple(_lib.SMALL_ACT[m[2]] for m in maps)
-    scales = tuple(float(m[3]) for m in maps)
-    wb = []
-    for m in maps:
-        wb += [m[0], m[1]]
-    return SmallLinearGroupFn.apply(x, acts, scales, *wb)
+    out = ()
+    for i in range(0, len(maps), _lib.SMALL_MAX):
+        grp = maps[i:i + _lib.SMALL_MAX]
+        acts = tuple(_lib.SMALL_ACT[m[2]] for m in grp)
+        scales = tuple(float(m[3]) for m in grp)
+        wb = []
+        for m in grp:
+            wb += [m[0], m[1]]
+        out += SmallLinearGroupFn.apply(x, acts, scales, *wb)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
