@@ -82,6 +82,17 @@ int unet_conv1d_pack(int32_t dtype, const float* w, int64_t tap_stride, int64_t 
 int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void* x2, const void* w_packed,
                     const float* bias, const void* res, void* y, void* stream);
 
+/* unet_conv1d_fwd that also emits the batch statistics of its output, so that the BatchNorm which follows
+ * (models.py:801-817) needs no pass of its own over y: s1_part / s2_part [n][*parts_out][c_out] fp32 = sum and sum of
+ * squares of the STORED values (after bias / residual / activation, rounded to the output dtype) over the positions
+ * of one tile.  Buffers must hold unet_conv1d_stats_max_parts(d) * n * c_out floats each.  *parts_out = 0 means the
+ * kernel chosen for this conv does not produce them (generic / fp32 / streaming / transposed): y is complete, the
+ * caller computes the statistics with unet_rowstats. */
+int32_t unet_conv1d_stats_max_parts(const UnetConvDesc* d);
+int unet_conv1d_fwd_stats(const UnetConvDesc* d, const void* x1, const void* x2, const void* w_packed,
+                          const float* bias, const void* res, void* y, float* s1_part, float* s2_part,
+                          int32_t* parts_out, void* stream);
+
 /* Which kernel the calling thread's most recent unet_conv1d_fwd / unet_conv1d_wgrad launch used.  No
  * counterpart in the reference (cuDNN picks its algorithm internally, models.py convs); bench.py uses it
  * to attribute live launch timings to the kernel named in its roofline object. */

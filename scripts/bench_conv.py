@@ -175,6 +175,10 @@ def main():
                 wp = ops.pack_weights(w, ops._dt(x), transpose=False, tap_src=None, n_taps=geom.n_taps, row_lo=0,
                                       rows=cout, c1=cin, c2=0)
                 fn = lambda: ops.conv_forward_raw(geom, x, None, wp, None, None, l_out, cout)
+            elif k == "fwdstats":   # forward with the BatchNorm statistics from the epilogue (UNET_EPILOGUE_STATS=0: without)
+                wp = ops.pack_weights(w, ops._dt(x), transpose=False, tap_src=None, n_taps=geom.n_taps, row_lo=0,
+                                      rows=cout, c1=cin, c2=0)
+                fn = lambda: ops.conv_forward_raw(geom, x, None, wp, None, None, l_out, cout, want_stats=True)
             elif k == "dgrad":
                 gd, src = geom.dgrad()
                 wp = ops.pack_weights(w, ops._dt(x), transpose=True, tap_src=src, n_taps=geom.n_taps, row_lo=0,

@@ -308,3 +308,37 @@ def test_batchnorm_act_se_node_matches_torch(dtype, shape):
 def ops_act_id(name):
     from unet_amd.model import ACT_IDS
     return ACT_IDS[name]
+
+
+@pytest.mark.parametrize("shape", [(3, 700, 64, 128, 1), (2, 4096, 256, 256, 1), (2, 1000, 128, 320, 2)])
+def test_conv_epilogue_statistics(shape):
+    """unet_conv1d_fwd_stats: the per-tile sum / sum of squares written by the conv epilogue equal those of a pass over
+    the stored bf16 output (unet_rowstats), ragged last tile and a partial channel slab included; the BatchNorm node
+    picks them up (STATS_HINT_HITS) and produces the same result as with its own statistics pass."""
+    ops = _ops()
+    n, l, cin, cout, stride = shape
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(n, l, cin, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(3, cout, cin, device="cuda", generator=g) * 0.05).requires_grad_(True)
+    b = torch.randn(cout, device="cuda", generator=g).requires_grad_(True)
+    geom = ops.geom_conv(3, stride)
+    l_out = ops.conv_out_len(l, 3, stride)
+    y = ops.conv(x, w, b, geom, l_out, want_stats=True)
+    hint = ops._take_stats(y)
+    assert hint is not None, "the tiled bf16 kernel must deliver statistics for this conv"
+    s1, s2 = (t.double().sum(dim=1) for t in hint)
+    r1, r2 = ops.rowstats(y.detach())
+    assert torch.allclose(s1, r1, rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s2, r2, rtol=1e-5, atol=1e-3)
+
+    gamma, beta = torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda")
+    outs = []
+    for use in (True, False):
+        y = ops.conv(x, w, b, geom, l_out, want_stats=use)
+        hits = ops.STATS_HINT_HITS
+        rm, rv = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")
+        z = ops.BatchNormActFn.apply(y, gamma, beta, rm, rv, 0.1, 1e-5, ops_act_id("gelu"), False)
+        assert (ops.STATS_HINT_HITS - hits) == (1 if use else 0)
+        outs.append((z, rm, rv))
+    assert rel(outs[0][0], outs[1][0]) < 1e-5
+    assert rel(outs[0][1], outs[1][1]) < 1e-5 and rel(outs[0][2], outs[1][2]) < 1e-5

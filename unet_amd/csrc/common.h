@@ -1,5 +1,6 @@
 // Shared device/host helpers for libunet_hip (gfx950 only).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -166,6 +167,19 @@ __device__ __forceinline__ void act_both(int act, float x, float& f, float& d) {
     f = act_fwd(act, x);
     d = act_bwd(act, x);
   }
+}
+
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane of the row: four v_add_f32 with DPP
+// operands (quad swaps, half-row mirror, row mirror), no LDS traffic -- __shfl_xor would be a ds_bpermute per step
+__device__ __forceinline__ float row16_sum(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+  return v;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -48,6 +48,7 @@ struct ConvK {
   int xdb;               // input tile double-buffered
   int xbytes;            // bytes of one input tile buffer (multiple of 1 KiB)
   int tap_row[UNET_MAX_TAPS];  // LDS row that local output position 0 reads for this tap
+  float* s1; float* s2;  // conv_fwd2 only, optional: per-(window, position tile, channel) sum / sum of squares of y
 };
 
 __device__ const u32x4 g_zero_chunk = {0u, 0u, 0u, 0u};  // source of padding rows for LDS-DMA staging
@@ -481,6 +482,12 @@ __device__ __forceinline__ void conv_fwd2_body(const ConvK& p) {
   T* ybase = reinterpret_cast<T*>(p.y) + (long long)n * p.y_ns;
   const T* rbase = p.res ? reinterpret_cast<const T*>(p.res) + (long long)n * p.res_ns : nullptr;
   const int mcount = p.mcount[phase];
+  const bool stats = p.s1 != nullptr;
+  float st1[4][4], st2[4][4];          // per-channel sum / sum of squares of the values this lane stores
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st1[mi][r] = 0.f; st2[mi][r] = 0.f; }
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int m = m0 + wn * (BN / 2) + ni * 16 + l15;
@@ -515,6 +522,14 @@ __device__ __forceinline__ void conv_fwd2_body(const ConvK& p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = act_fwd(p.act, v[r]);
       }
+      if (stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float q = to_f32(from_f32<T>(v[r]));      // the value as stored: what a pass over y would read
+          st1[mi][r] += q;
+          st2[mi][r] = fmaf(q, q, st2[mi][r]);
+        }
+      }
       T* yp = ybase + o * p.y_ld + co;
       if (full && p.y_vec) {
         VecIO<T, 4>::store(yp, v);
@@ -522,6 +537,30 @@ __device__ __forceinline__ void conv_fwd2_body(const ConvK& p) {
         for (int r = 0; r < 4; ++r)
           if (co + r < p.c_out) yp[r] = from_f32<T>(v[r]);
       }
+    }
+  }
+  // ---- optional: the tile's per-channel sum and sum of squares (BatchNorm statistics, models.py:801-817), so that
+  // no separate pass has to read y back: 16 positions across the lanes of a row, the two position halves of the
+  // tile across waves through LDS, one fp32 partial per (window, position tile, channel) ----------------------
+  if (stats) {       // block-uniform
+    __syncthreads();   // every wave is past its last fragment read: the LDS is free
+    float* sred = reinterpret_cast<float*>(smem);          // [2 position halves][128 channels][2]
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum(st1[mi][r]), b = row16_sum(st2[mi][r]);
+        if (l15 == 0) {
+          const int ch = wm * 64 + mi * 16 + lq * 4 + r;
+          sred[(wn * BM + ch) * 2] = a;
+          sred[(wn * BM + ch) * 2 + 1] = b;
+        }
+      }
+    __syncthreads();
+    const int ch = tid >> 1, which = tid & 1, co = mt * BM + ch;
+    if (co < p.c_out) {
+      float* dst = which ? p.s2 : p.s1;
+      dst[((long long)n * ppw + pt) * p.c_out + co] = sred[ch * 2 + which] + sred[(BM + ch) * 2 + which];
     }
   }
 }
@@ -1385,9 +1424,33 @@ namespace { thread_local int g_last_variant = 0; }
 // which kernel the calling thread's most recent conv launch used (profiling aid; see include/unet_hip.h)
 extern "C" int unet_conv1d_last_variant(void) { return g_last_variant; }
 
+namespace {
+int conv_fwd_impl(const UnetConvDesc* d, const void* x1, const void* x2, const void* w_packed, const float* bias,
+                  const void* res, void* y, float* s1_part, float* s2_part, int32_t* parts_out, void* stream);
+}
+
 extern "C" int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void* x2, const void* w_packed,
                                const float* bias, const void* res, void* y, void* stream) {
+  return conv_fwd_impl(d, x1, x2, w_packed, bias, res, y, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int32_t unet_conv1d_stats_max_parts(const UnetConvDesc* d) {
+  UNET_REQUIRE(d, "conv_stats_max_parts: null pointer");
+  return d->up == 1 && d->dtype == UNET_BF16 ? cdiv(d->l_out, 64) : 0;
+}
+
+extern "C" int unet_conv1d_fwd_stats(const UnetConvDesc* d, const void* x1, const void* x2, const void* w_packed,
+                                     const float* bias, const void* res, void* y, float* s1_part, float* s2_part,
+                                     int32_t* parts_out, void* stream) {
+  UNET_REQUIRE(s1_part && s2_part && parts_out, "conv_fwd_stats: null pointer");
+  return conv_fwd_impl(d, x1, x2, w_packed, bias, res, y, s1_part, s2_part, parts_out, stream);
+}
+
+namespace {
+int conv_fwd_impl(const UnetConvDesc* d, const void* x1, const void* x2, const void* w_packed, const float* bias,
+                  const void* res, void* y, float* s1_part, float* s2_part, int32_t* parts_out, void* stream) {
   UNET_REQUIRE(d && x1 && w_packed && y, "conv_fwd: null pointer");
+  if (parts_out) *parts_out = 0;
   Phases ph;
   if (analyse(d, &ph)) return -1;
   UNET_REQUIRE(d->c2 == 0 || x2, "conv_fwd: c2>0 but x2 is null");
@@ -1397,6 +1460,8 @@ extern "C" int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void
   k.x1 = static_cast<const char*>(x1); k.x2 = static_cast<const char*>(x2);
   k.wp = static_cast<const char*>(w_packed); k.bias = bias; k.res = static_cast<const char*>(res);
   k.y = static_cast<char*>(y);
+  k.s1 = k.s2 = nullptr;
+  const bool want_stats = s1_part && d->up == 1;       // only the tiled bf16 kernel below produces them
   k.x1_ns = d->x1_ns; k.x2_ns = d->x2_ns; k.y_ns = d->y_ns; k.res_ns = d->res_ns;
   k.x1_ld = d->x1_ld; k.x2_ld = d->x2_ld; k.y_ld = d->y_ld; k.res_ld = d->res_ld;
   k.c1 = d->c1; k.c2 = d->c2;
@@ -1464,12 +1529,14 @@ extern "C" int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void
           }
           for (int j = 0; j < UNET_MAX_TAPS; ++j) k.tap_row[j] = tg2.tap_row[j];
           g_last_variant = UNET_VARIANT_FWD_TILED;
+          if (want_stats) { k.s1 = s1_part; k.s2 = s2_part; *parts_out = k.ptiles[0]; }
           return launch_fwd2<192>(k, tg2.rmax, st);
         }
       }
     }
     if (v2) {
       g_last_variant = UNET_VARIANT_FWD_TILED;
+      if (want_stats) { k.s1 = s1_part; k.s2 = s2_part; *parts_out = k.ptiles[0]; }
       return bn == 128 ? launch_fwd2<128>(k, tg.rmax, st) : launch_fwd2<64>(k, tg.rmax, st);
     }
   }
@@ -1477,6 +1544,7 @@ extern "C" int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void
   if (d->dtype == UNET_F32) return bn == 128 ? launch_fwd<true, 128>(k, tg.rmax, st) : launch_fwd<true, 64>(k, tg.rmax, st);
   return bn == 128 ? launch_fwd<false, 128>(k, tg.rmax, st) : launch_fwd<false, 64>(k, tg.rmax, st);
 }
+}  // namespace
 
 namespace {
 int wgrad_splits(const UnetConvDesc* d, const Phases& ph) {

@@ -60,6 +60,11 @@ def _as_ncl(x: Tensor) -> Tensor:
 # ---------------------------------------------------------------------------------------------
 # normalisation (models.py:537-555, 801-817) + activation (+ SE squeeze) on the HIP kernels
 # ---------------------------------------------------------------------------------------------
+def _uses_batch_stats(norm: nn.Module) -> bool:
+    """BatchNorm that normalises with the statistics of its own input: the conv in front of it can deliver them."""
+    return isinstance(norm, nn.BatchNorm1d) and (norm.training or norm.running_mean is None) and torch.is_grad_enabled()
+
+
 def _make_norm(norm_type: str, c: int) -> nn.Module:
     if norm_type == "instance":
         return nn.InstanceNorm1d(c, affine=True)
@@ -426,7 +431,7 @@ class ConvBlock(nn.Module):
         c = self.conv[0]
         l_out = ops.conv_out_len(x1.shape[1], 3, self.stride)
         return ops.conv(x1, c.weight.permute(2, 0, 1), c.bias, ops.geom_conv(3, self.stride), l_out, x2=x2,
-                        params=(c.weight, c.bias))
+                        params=(c.weight, c.bias), want_stats=_uses_batch_stats(self.conv[1]))
 
     def forward_nlc(self, x1: Tensor, emb: Optional[Tensor], x2: Optional[Tensor] = None) -> Tensor:
         y = self._main_conv(x1, x2)
@@ -512,10 +517,11 @@ class MultiScaleDilatedConv1d(nn.Module):
         b_eff = (torch.stack([b.conv.bias for b in self.branches], dim=0).float() * w[:, None]).sum(0)
         return w_eff, b_eff
 
-    def forward_nlc(self, x1: Tensor, x2: Optional[Tensor] = None) -> Tensor:
+    def forward_nlc(self, x1: Tensor, x2: Optional[Tensor] = None, want_stats: bool = False) -> Tensor:
         k, s = self.kernel_size, self.stride
         l_out = ops.conv_out_len(x1.shape[1], k, s, 1)
-        return ops.conv(x1, self.effective_weights, None, self._geom, l_out, x2=x2, params=tuple(self.parameters()))
+        return ops.conv(x1, self.effective_weights, None, self._geom, l_out, x2=x2, params=tuple(self.parameters()),
+                        want_stats=want_stats)
 
     def forward(self, x: Tensor) -> Tensor:
         return _as_ncl(self.forward_nlc(_to_nlc(x)))
@@ -542,7 +548,7 @@ class ModernConvBlock(nn.Module):
         self.film = FiLM(out_c, emb_dim, cond_mode=cond_mode)
 
     def forward_nlc(self, x1: Tensor, emb: Optional[Tensor], x2: Optional[Tensor] = None) -> Tensor:
-        y = self.conv[0].forward_nlc(x1, x2)
+        y = self.conv[0].forward_nlc(x1, x2, want_stats=_uses_batch_stats(self.conv[1]))
         if self.use_se:
             z = _norm_act_se(y, self.conv[1], ACT_IDS["gelu"], self.conv[3])
         else:

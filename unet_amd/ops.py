@@ -259,9 +259,12 @@ def pack_weights(w: Tensor, dtype: int, *, transpose: bool, tap_src: Optional[Se
 
 
 def conv_forward_raw(geom: ConvGeom, x1: Tensor, x2: Optional[Tensor], w_packed: Tensor, bias: Optional[Tensor],
-                     res: Optional[Tensor], l_out: int, c_out: int, act: int = 0, out: Optional[Tensor] = None) -> Tensor:
+                     res: Optional[Tensor], l_out: int, c_out: int, act: int = 0, out: Optional[Tensor] = None,
+                     want_stats: bool = False) -> Tensor:
     """``out``: write into this [N, l_out, c_out] tensor (any batch / row pitch with unit channel stride) instead of a
-    new one -- how a group of convs fills one buffer without a gather afterwards."""
+    new one -- how a group of convs fills one buffer without a gather afterwards.
+    ``want_stats``: a BatchNorm follows; where the kernel can, it emits the per-tile sum / sum of squares of y from its
+    epilogue and they travel beside y (``_take_stats``) so that the norm skips its statistics pass."""
     lib = _lib.load()
     if out is not None:
         if tuple(out.shape) != (x1.shape[0], l_out, c_out) or out.dtype != x1.dtype or out.stride(2) != 1:
@@ -270,9 +273,19 @@ def conv_forward_raw(geom: ConvGeom, x1: Tensor, x2: Optional[Tensor], w_packed:
     else:
         y = torch.empty((x1.shape[0], l_out, c_out), dtype=x1.dtype, device=x1.device)
     d = _desc(geom, x1, x2, y, res, act)
+    max_parts = int(lib.unet_conv1d_stats_max_parts(C.byref(d))) if (want_stats and EPILOGUE_STATS) else 0
     with _Timed("conv_fwd", geom.alg_flops(d.n, l_out, c_out, d.c1 + d.c2), geom.alg_scale):
-        check(lib.unet_conv1d_fwd(C.byref(d), _p(x1), _p(x2), _p(w_packed), _p(bias), _p(res), _p(y), _stream()),
-              "unet_conv1d_fwd")
+        if max_parts > 0:
+            sbuf = torch.empty((2, d.n * max_parts * c_out), dtype=torch.float32, device=x1.device)
+            got = C.c_int32(0)
+            check(lib.unet_conv1d_fwd_stats(C.byref(d), _p(x1), _p(x2), _p(w_packed), _p(bias), _p(res), _p(y),
+                                            _p(sbuf[0]), _p(sbuf[1]), C.byref(got), _stream()), "unet_conv1d_fwd_stats")
+            if got.value > 0:
+                k = d.n * got.value * c_out
+                _offer_stats(y, sbuf[0, :k].view(d.n, got.value, c_out), sbuf[1, :k].view(d.n, got.value, c_out))
+        else:
+            check(lib.unet_conv1d_fwd(C.byref(d), _p(x1), _p(x2), _p(w_packed), _p(bias), _p(res), _p(y), _stream()),
+                  "unet_conv1d_fwd")
     return y
 
 
@@ -312,6 +325,29 @@ _BIAS_HINT = {}
 BIAS_HINT_HITS = 0          # diagnostic: how many conv bias gradients came from a hand-off
 
 
+EPILOGUE_STATS = os.environ.get("UNET_EPILOGUE_STATS", "1") != "0"   # 0: separate statistics pass (A/B measurements)
+_STATS_HINT = {}
+
+
+def _offer_stats(y: Tensor, s1p: Tensor, s2p: Tensor):
+    """Same hand-off for BatchNorm statistics: the conv that wrote ``y`` also wrote its per-tile sum / sum of squares."""
+    if len(_STATS_HINT) > 64:
+        _STATS_HINT.clear()
+    _STATS_HINT[id(y)] = (weakref.ref(y), s1p, s2p)
+
+
+STATS_HINT_HITS = 0          # diagnostic: how many BatchNorm statistics came from a conv epilogue
+
+
+def _take_stats(y: Tensor):
+    global STATS_HINT_HITS
+    h = _STATS_HINT.pop(id(y), None)
+    if h is not None and h[0]() is y and h[1].shape[0] == y.shape[0] and h[1].shape[2] == y.shape[2]:
+        STATS_HINT_HITS += 1
+        return h[1], h[2]
+    return None
+
+
 def _offer_colsum(dy: Tensor, parts: Tensor):
     if len(_BIAS_HINT) > 64:
         _BIAS_HINT.clear()
@@ -329,7 +365,7 @@ class ConvFn(torch.autograd.Function):
     """y = conv(geom; [x1 | x2], w[J, Cout, C1+C2], bias) (+ res).  See include/unet_hip.h."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w, bias, res, geom: ConvGeom, l_out: int):
+    def forward(ctx, x1, x2, w, bias, res, geom: ConvGeom, l_out: int, want_stats: bool = False):
         _need_cuda(x1)
         x1 = _nlc_ok(x1)
         x2 = _nlc_ok(x2) if x2 is not None else None
@@ -345,7 +381,7 @@ class ConvFn(torch.autograd.Function):
             wf = wf.float()
         wp = pack_weights(wf, dt, transpose=False, tap_src=None, n_taps=j, row_lo=0, rows=c_out, c1=c1, c2=c2)
         b = _f32c(bias) if bias is not None else None
-        y = conv_forward_raw(geom, x1, x2, wp, b, res, l_out, c_out)
+        y = conv_forward_raw(geom, x1, x2, wp, b, res, l_out, c_out, want_stats=want_stats)
         ctx.geom, ctx.l_out = geom, l_out
         ctx.has_x2, ctx.has_bias, ctx.has_res = x2 is not None, bias is not None, res is not None
         ctx.w_dtype = w.dtype
@@ -379,7 +415,7 @@ class ConvFn(torch.autograd.Function):
             dx1 = conv_dgrad_raw(geom, wf, dy, l_in, 0, c1)
         if ctx.has_x2 and ctx.needs_input_grad[1]:
             dx2 = conv_dgrad_raw(geom, wf, dy, l_in, c1, c2)
-        return dx1, dx2, dw, db, dres, None, None
+        return dx1, dx2, dw, db, dres, None, None, None
 
 
 # Packed-weight cache for INFERENCE.  A training step must repack every weight (the optimizer has just changed it; the
@@ -416,7 +452,7 @@ def packed_for_inference(tag, params: Sequence[Tensor], dtype: int, build):
 
 
 def conv(x1: Tensor, w, bias: Optional[Tensor], geom: ConvGeom, l_out: int, x2: Optional[Tensor] = None,
-         res: Optional[Tensor] = None, params: Optional[Sequence[Tensor]] = None) -> Tensor:
+         res: Optional[Tensor] = None, params: Optional[Sequence[Tensor]] = None, want_stats: bool = False) -> Tensor:
     """``w``: [J, Cout, C1+C2] weights, or a callable returning ``(w, bias)`` (weights that take work to derive: the
     merged dilated taps, the transposed conv's tap order).  ``params``: the parameters ``w`` and ``bias`` derive
     from; given, inference calls reuse the packed image instead of rebuilding it (see above)."""
@@ -439,7 +475,7 @@ def conv(x1: Tensor, w, bias: Optional[Tensor], geom: ConvGeom, l_out: int, x2: 
         wp, b32, c_out = packed_for_inference(("conv", geom, c1, c2), params, dt, build)
         return conv_forward_raw(geom, x1, x2, wp, b32, res, l_out, c_out)
     wv, bv = w() if callable(w) else (w, bias)
-    return ConvFn.apply(x1, x2, wv, bv, res, geom, l_out)
+    return ConvFn.apply(x1, x2, wv, bv, res, geom, l_out, want_stats)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -605,8 +641,12 @@ class BatchNormActFn(torch.autograd.Function):
         y = y.contiguous()
         n, rows, c = y.shape
         dt, st = _dt(y), _stream()
-        s1p, s2p = _part_buf(y, 2)
-        check(lib.unet_rowstats(dt, _p(y), _p(s1p), _p(s2p), n, rows, c, st), "unet_rowstats")
+        hint = _take_stats(y)
+        if hint is not None:
+            s1p, s2p = hint
+        else:
+            s1p, s2p = _part_buf(y, 2)
+            check(lib.unet_rowstats(dt, _p(y), _p(s1p), _p(s2p), n, rows, c, st), "unet_rowstats")
         coef = torch.empty((4, n, c), dtype=torch.float32, device=y.device)
         mean, rstd, a, b = coef[0], coef[1], coef[2], coef[3]
         gf = _f32c(gamma) if gamma is not None else None
@@ -615,7 +655,7 @@ class BatchNormActFn(torch.autograd.Function):
                                        _p(running_mean), _p(running_var), momentum, _p(mean), _p(rstd), _p(a), _p(b),
                                        st), "unet_bn_finalize_fwd")
         z = torch.empty_like(y)
-        pbuf = s1p if want_pool else None  # partial buffer no longer needed: reuse
+        pbuf = (s1p if hint is None else _part_buf(y)[0]) if want_pool else None  # own partial buffer no longer needed: reuse
         check(lib.unet_affine_act_fwd(dt, _p(y), _p(a), _p(b), act_id, _p(z), _p(pbuf), n, rows, c, st),
               "unet_affine_act_fwd")
         ctx.act_id, ctx.want_pool = act_id, want_pool
@@ -676,8 +716,12 @@ class BatchNormActSEFn(torch.autograd.Function):
         y = y.contiguous()
         n, rows, c = y.shape
         dt, st = _dt(y), _stream()
-        s1p, s2p = _part_buf(y, 2)
-        check(lib.unet_rowstats(dt, _p(y), _p(s1p), _p(s2p), n, rows, c, st), "unet_rowstats")
+        hint = _take_stats(y)
+        if hint is not None:
+            s1p, s2p = hint
+        else:
+            s1p, s2p = _part_buf(y, 2)
+            check(lib.unet_rowstats(dt, _p(y), _p(s1p), _p(s2p), n, rows, c, st), "unet_rowstats")
         coef = torch.empty((4, n, c), dtype=torch.float32, device=y.device)
         mean, rstd, a, b = coef[0], coef[1], coef[2], coef[3]
         gf = _f32c(gamma) if gamma is not None else None
@@ -685,8 +729,9 @@ class BatchNormActSEFn(torch.autograd.Function):
         check(lib.unet_bn_finalize_fwd(_p(s1p), _p(s2p), n, s1p.shape[1], c, rows, eps, _p(gf), _p(bf),
                                        _p(running_mean), _p(running_var), momentum, _p(mean), _p(rstd), _p(a), _p(b),
                                        st), "unet_bn_finalize_fwd")
-        check(lib.unet_affine_pool(dt, _p(y), _p(a), _p(b), act_id, _p(s1p), n, rows, c, st), "unet_affine_pool")
-        pool = sum_parts(s1p)
+        pbuf = s1p if hint is None else _part_buf(y)[0]
+        check(lib.unet_affine_pool(dt, _p(y), _p(a), _p(b), act_id, _p(pbuf), n, rows, c, st), "unet_affine_pool")
+        pool = sum_parts(pbuf)
         # the SE MLP (models.py:660-661) by raw launches; its backward runs in the middle of this node's backward
         w0f, w2f = _f32c(w0), _f32c(w2)
         gelu, sig = _lib.SMALL_ACT["gelu"], _lib.SMALL_ACT["sigmoid"]
