@@ -36,6 +36,7 @@ def main():
         parts = int(libs[0].unet_parts(rows))
         p1 = torch.empty(n, parts, c, device="cuda")
         p2 = torch.empty_like(p1)
+        p5 = torch.empty(5, n, parts, c, device="cuda")
         nb = y.numel() * 2
         cases = [
             ("rowstats", 1, lambda L: L.unet_rowstats(0, P(y), P(p1), P(p2), n, rows, c, st)),
@@ -43,6 +44,10 @@ def main():
             ("affine_act_fwd+pool", 2, lambda L: L.unet_affine_act_fwd(0, P(y), P(a), P(b), 3, P(o1), P(p1), n, rows, c, st)),
             ("affine_act_bwd_reduce", 2, lambda L: L.unet_affine_act_bwd_reduce(0, P(y), P(dz), None, P(a), P(b), 3, P(p1), P(p2), n, rows, c, st)),
             ("affine_act_bwd_apply", 3, lambda L: L.unet_affine_act_bwd_apply(0, P(y), P(dz), None, P(a), P(b), 3, P(a), P(b), P(b), P(o1), n, rows, c, st)),
+            ("affine_pool", 1, lambda L: L.unet_affine_pool(0, P(y), P(a), P(b), 3, P(p1), n, rows, c, st)),
+            ("affine_act_scale_fwd", 2, lambda L: L.unet_affine_act_scale_fwd(0, P(y), P(a), P(b), 3, P(a), P(o1), n, rows, c, st)),
+            ("se_bwd_reduce", 2, lambda L: L.unet_affine_act_se_bwd_reduce(0, P(y), P(dz), P(a), P(b), 3, P(p5), n, rows, c, st)),
+            ("se_bwd_apply", 3, lambda L: L.unet_affine_act_se_bwd_apply(0, P(y), P(dz), P(b), P(a), P(a), P(b), 3, P(a), P(b), P(b), P(o1), P(p1), n, rows, c, st)),
             ("scale_fwd", 2, lambda L: L.unet_scale_fwd(0, P(y), P(a), P(o1), n, rows, c, st)),
             ("scale_bwd", 3, lambda L: L.unet_scale_bwd(0, P(y), P(dz), P(a), P(o1), P(p1), n, rows, c, st)),
             ("gated_add_fwd", 3, lambda L: L.unet_gated_add_fwd(0, P(y), P(dz), P(a), P(o1), n, rows, c, st)),

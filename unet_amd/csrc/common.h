@@ -169,6 +169,27 @@ __device__ __forceinline__ void act_both(int act, float x, float& f, float& d) {
   }
 }
 
+// The same with the activation known at compile time (ACT >= 0) or at run time (ACT < 0).  The streaming kernels
+// evaluate it per element inside their row loop: with a run-time switch there the compiler keeps one branchy basic
+// block per element (49 VALU instructions per GELU on the ISA, no packed math); specialised, the eight elements of a
+// vector are straight-line code it can interleave and pack.
+template <int ACT> __device__ __forceinline__ float act_fwd_t(int act, float x) {
+  if constexpr (ACT == UNET_ACT_GELU) { float c, e; gelu_cdf(x, c, e); return x * c; }
+  else return act_fwd(act, x);
+}
+template <int ACT> __device__ __forceinline__ float act_bwd_t(int act, float x) {
+  if constexpr (ACT == UNET_ACT_GELU) { float c, e; gelu_cdf(x, c, e); return fmaf(x * 0.3989422804014327f, e, c); }
+  else return act_bwd(act, x);
+}
+template <int ACT> __device__ __forceinline__ void act_both_t(int act, float x, float& f, float& d) {
+  if constexpr (ACT == UNET_ACT_GELU) {
+    float c, e;
+    gelu_cdf(x, c, e);
+    f = x * c;
+    d = fmaf(x * 0.3989422804014327f, e, c);
+  } else act_both(act, x, f, d);
+}
+
 // sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane of the row: four v_add_f32 with DPP
 // operands (quad swaps, half-row mirror, row mirror), no LDS traffic -- __shfl_xor would be a ds_bpermute per step
 __device__ __forceinline__ float row16_sum(float v) {

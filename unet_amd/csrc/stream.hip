@@ -23,7 +23,7 @@ template <class OP>
 __global__ __launch_bounds__(THREADS) void rowstream_kernel(OP op, int rows, int c, int parts) {
   constexpr int V = OP::V;
   constexpr int NR = OP::NRED;
-  __shared__ float red_s[(NR > 0 ? NR : 1) * V * THREADS];
+  __shared__ float red_s[(NR > 0 ? NR : 1) * V * (THREADS + 8)];
   const int n = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
   const int cv = c / V;
   const int cvb = cv < THREADS ? cv : THREADS;
@@ -53,6 +53,9 @@ __global__ __launch_bounds__(THREADS) void rowstream_kernel(OP op, int rows, int
         float in[U][NIN][V];
 #pragma unroll
         for (int u = 0; u < U; ++u) op.ld(base + (long long)(r + u * RL) * c, in[u]);
+        // keep every load of the iteration above the arithmetic (left alone, the scheduler sank some of them next to
+        // their first use behind a vmcnt(0): measured +20 % on the norm-backward apply pass)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; ++u) op.row(st, base + (long long)(r + u * RL) * c, in[u], acc);
       }
@@ -63,22 +66,23 @@ __global__ __launch_bounds__(THREADS) void rowstream_kernel(OP op, int rows, int
       }
     }
     if constexpr (NR > 0) {
+      // block-level sum over the RL row lanes: every thread owns a few (sum, channel) outputs (with one thread per
+      // column group doing all NR * V of them the tail of a five-sum pass was 320 serial LDS reads on 32 lanes)
+      constexpr int LDP = THREADS + 8;      // row pitch: 64 consecutive outputs (8 channels x 8 column groups) read 64 banks
 #pragma unroll
       for (int k = 0; k < NR; ++k)
 #pragma unroll
-        for (int v = 0; v < V; ++v) red_s[(k * V + v) * THREADS + tid] = acc[k][v];
+        for (int v = 0; v < V; ++v) red_s[(k * V + v) * LDP + tid] = acc[k][v];
       __syncthreads();
-      if (rl == 0 && active) {
-        float sums[NR][V];
-#pragma unroll
-        for (int k = 0; k < NR; ++k)
-#pragma unroll
-          for (int v = 0; v < V; ++v) {
-            float s = 0.f;
-            for (int j = 0; j < RL; ++j) s += red_s[(k * V + v) * THREADS + j * cvb + cgl];
-            sums[k][v] = s;
-          }
-        op.write_part(((long long)n * parts + part) * c + cg * V, sums);
+      const long long obase = ((long long)n * parts + part) * c;
+      for (int idx = tid; idx < NR * V * cvb; idx += THREADS) {
+        const int v = idx % V, g2 = (idx / V) % cvb, k = idx / (V * cvb);
+        if (cb + g2 < cv) {
+          const float* src = red_s + (k * V + v) * LDP + g2;
+          float sum = 0.f;
+          for (int j = 0; j < RL; ++j) sum += src[j * cvb];
+          op.part(k)[obase + (long long)(cb + g2) * V + v] = sum;
+        }
       }
       __syncthreads();
     }
@@ -109,9 +113,7 @@ template <typename T, int V_> struct RowStatsOp : OpBase<T, V_> {
 #pragma unroll
     for (int i = 0; i < V_; ++i) { acc[0][i] += in[0][i]; acc[1][i] += in[0][i] * in[0][i]; }
   }
-  __device__ void write_part(long long e, const float (&s)[2][V_]) const {
-    this->stc(s1 + e, s[0]); this->stc(s2 + e, s[1]);
-  }
+  __device__ float* part(int k) const { return k ? s2 : s1; }
 };
 
 // ---- column sum --------------------------------------------------------------------------------
@@ -125,11 +127,11 @@ template <typename T, int V_> struct ColSumOp : OpBase<T, V_> {
 #pragma unroll
     for (int i = 0; i < V_; ++i) acc[0][i] += in[0][i];
   }
-  __device__ void write_part(long long e, const float (&s)[1][V_]) const { this->stc(out + e, s[0]); }
+  __device__ float* part(int) const { return out; }
 };
 
 // ---- z = act(a*y+b), pool = sum z -----------------------------------------------------------------
-template <typename T, int V_, bool POOL> struct AffineActFwdOp : OpBase<T, V_> {
+template <typename T, int V_, bool POOL, int ACT = -1> struct AffineActFwdOp : OpBase<T, V_> {
   static constexpr int NRED = POOL ? 1 : 0, NIN = 1;
   const T* y; T* z; const float* a; const float* b; float* pool; int act;
   struct State { float a[V_], b[V_]; };
@@ -141,17 +143,17 @@ template <typename T, int V_, bool POOL> struct AffineActFwdOp : OpBase<T, V_> {
     float f[V_];
 #pragma unroll
     for (int i = 0; i < V_; ++i) {
-      f[i] = act_fwd(act, s.a[i] * in[0][i] + s.b[i]);
+      f[i] = act_fwd_t<ACT>(act, s.a[i] * in[0][i] + s.b[i]);
       if (POOL) acc[0][i] += f[i];
     }
     VecIO<T, V_>::store(z + e, f);
   }
-  __device__ void write_part(long long e, const float (&s)[1][V_]) const { this->stc(pool + e, s[0]); }
+  __device__ float* part(int) const { return pool; }
 };
 
 // ---- backward of the above ---------------------------------------------------------------------
 // SC: dz is the gradient of z = act(a*y+b)*sc (the squeeze-excite gate folded in): g = (dz*sc + dpool) * act'
-template <typename T, int V_, bool APPLY, bool BSUM = false, bool SC = false> struct AffineActBwdOp : OpBase<T, V_> {
+template <typename T, int V_, bool APPLY, bool BSUM = false, bool SC = false, int ACT = -1> struct AffineActBwdOp : OpBase<T, V_> {
   static constexpr int NRED = APPLY ? (BSUM ? 1 : 0) : 2, NIN = 2;
   const float* sc = nullptr;
   static constexpr int UNROLL = APPLY ? 4 : 2;   // the reduce pass at 4 rows crosses 128 VGPRs and loses a wave per SIMD (measured +10 %)
@@ -181,7 +183,7 @@ template <typename T, int V_, bool APPLY, bool BSUM = false, bool SC = false> st
     for (int i = 0; i < V_; ++i) {
       const float fy = in[0][i];
       const float dzi = SC ? fmaf(in[1][i], s.sc[SC ? i : 0], s.dp[i]) : in[1][i] + s.dp[i];
-      const float g = dzi * act_bwd(act, s.a[i] * fy + s.b[i]);
+      const float g = dzi * act_bwd_t<ACT>(act, s.a[i] * fy + s.b[i]);
       if (APPLY) {
         out[i] = s.ca[i] * g + s.cb[i] * fy + s.cc[i];
         if (BSUM) acc[0][i] += out[i];
@@ -189,17 +191,14 @@ template <typename T, int V_, bool APPLY, bool BSUM = false, bool SC = false> st
     }
     if (APPLY) VecIO<T, V_>::store(dy + e, out);
   }
-  __device__ void write_part(long long e, const float (&s)[APPLY ? 1 : 2][V_]) const {
-    if (APPLY) { if (BSUM) this->stc(dysum + e, s[0]); }
-    else { this->stc(g1 + e, s[0]); this->stc(g2 + e, s[APPLY ? 0 : 1]); }
-  }
+  __device__ float* part(int k) const { return APPLY ? dysum : (k ? g2 : g1); }
 };
 
 // ---- norm + activation + squeeze-excite as one unit (models.py:801-839: norm, GELU, SE) -------------------------
 // z = act(a*y+b) * s[n][c] with s = SE-MLP(mean_l act(a*y+b)): the gate needs the whole window first, so forward is a
 // pool-only pass (1 read, nothing stored) and a fused pass (1 read, 1 write) -- the unscaled activation never exists
 // in HBM (norm+act+pool R/W followed by scale R/W: 4 touches -> 3).
-template <typename T, int V_> struct AffinePoolOp : OpBase<T, V_> {
+template <typename T, int V_, int ACT = -1> struct AffinePoolOp : OpBase<T, V_> {
   static constexpr int NRED = 1, NIN = 1;
   const T* y; const float* a; const float* b; float* pool; int act;
   struct State { float a[V_], b[V_]; };
@@ -209,11 +208,11 @@ template <typename T, int V_> struct AffinePoolOp : OpBase<T, V_> {
   __device__ void ld(long long e, float (&in)[1][V_]) const { VecIO<T, V_>::load(y + e, in[0]); }
   __device__ void row(State& s, long long, const float (&in)[1][V_], float (&acc)[1][V_]) const {
 #pragma unroll
-    for (int i = 0; i < V_; ++i) acc[0][i] += act_fwd(act, s.a[i] * in[0][i] + s.b[i]);
+    for (int i = 0; i < V_; ++i) acc[0][i] += act_fwd_t<ACT>(act, s.a[i] * in[0][i] + s.b[i]);
   }
-  __device__ void write_part(long long e, const float (&s)[1][V_]) const { this->stc(pool + e, s[0]); }
+  __device__ float* part(int) const { return pool; }
 };
-template <typename T, int V_> struct AffineActScaleFwdOp : OpBase<T, V_> {
+template <typename T, int V_, int ACT = -1> struct AffineActScaleFwdOp : OpBase<T, V_> {
   static constexpr int NRED = 0, NIN = 1;
   const T* y; T* z; const float* a; const float* b; const float* sc; int act;
   struct State { float a[V_], b[V_], sc[V_]; };
@@ -225,10 +224,10 @@ template <typename T, int V_> struct AffineActScaleFwdOp : OpBase<T, V_> {
   __device__ void row(State& s, long long e, const float (&in)[1][V_], float (&)[1][V_]) const {
     float f[V_];
 #pragma unroll
-    for (int i = 0; i < V_; ++i) f[i] = act_fwd(act, s.a[i] * in[0][i] + s.b[i]) * s.sc[i];
+    for (int i = 0; i < V_; ++i) f[i] = act_fwd_t<ACT>(act, s.a[i] * in[0][i] + s.b[i]) * s.sc[i];
     VecIO<T, V_>::store(z + e, f);
   }
-  __device__ void write_part(long long, const float (&)[1][V_]) const {}
+  __device__ float* part(int) const { return nullptr; }
 };
 // Backward, given dz = d loss / d z.  With u = a*y+b:  d s = sum_l dz*act(u), and the two sums the norm backward
 // needs, sum_l g and sum_l g*y with g = (dz*s + dpool)*act'(u), are LINEAR in the per-(window, channel) constants s
@@ -237,7 +236,7 @@ template <typename T, int V_> struct AffineActScaleFwdOp : OpBase<T, V_> {
 //   P0 = sum dz*act(u)   P1 = sum dz*act'(u)   P2 = sum dz*act'(u)*y   P3 = sum act'(u)   P4 = sum act'(u)*y,
 // and  sum g = s*P1 + dpool*P3,  sum g*y = s*P2 + dpool*P4  are formed on [N, C] afterwards (se_combine_kernel).
 // Replaces the SE-excite backward pass (3 touches) and the two-sum reduction pass (2 touches) by 2 touches.
-template <typename T, int V_> struct AffineActSEBwdReduceOp : OpBase<T, V_> {
+template <typename T, int V_, int ACT = -1> struct AffineActSEBwdReduceOp : OpBase<T, V_> {
   static constexpr int NRED = 5, NIN = 2;
   static constexpr int UNROLL = 2;
   const T* y; const T* dz; const float* a; const float* b; float* p; long long pstride; int act;
@@ -254,7 +253,7 @@ template <typename T, int V_> struct AffineActSEBwdReduceOp : OpBase<T, V_> {
     for (int i = 0; i < V_; ++i) {
       const float fy = in[0][i], d = in[1][i];
       float f, fp;
-      act_both(act, s.a[i] * fy + s.b[i], f, fp);
+      act_both_t<ACT>(act, s.a[i] * fy + s.b[i], f, fp);
       const float dfp = d * fp;
       acc[0][i] += d * f;
       acc[1][i] += dfp;
@@ -263,10 +262,7 @@ template <typename T, int V_> struct AffineActSEBwdReduceOp : OpBase<T, V_> {
       acc[4][i] += fp * fy;
     }
   }
-  __device__ void write_part(long long e, const float (&s)[5][V_]) const {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) this->stc(p + k * pstride + e, s[k]);
-  }
+  __device__ float* part(int k) const { return p + k * pstride; }
 };
 
 __global__ void se_combine_kernel(const float* __restrict__ p, long long nc, const float* __restrict__ s,
@@ -291,7 +287,7 @@ template <typename T, int V_> struct ScaleFwdOp : OpBase<T, V_> {
     for (int i = 0; i < V_; ++i) f[i] = in[0][i] * st.s[i];
     VecIO<T, V_>::store(out + e, f);
   }
-  __device__ void write_part(long long, const float (&)[1][V_]) const {}
+  __device__ float* part(int) const { return nullptr; }
 };
 template <typename T, int V_> struct ScaleBwdOp : OpBase<T, V_> {
   static constexpr int NRED = 1, NIN = 2;
@@ -308,7 +304,7 @@ template <typename T, int V_> struct ScaleBwdOp : OpBase<T, V_> {
     for (int i = 0; i < V_; ++i) { acc[0][i] += in[1][i] * in[0][i]; fd[i] = in[1][i] * st.s[i]; }
     VecIO<T, V_>::store(dx + e, fd);
   }
-  __device__ void write_part(long long e, const float (&sm)[1][V_]) const { this->stc(ds + e, sm[0]); }
+  __device__ float* part(int) const { return ds; }
 };
 
 // ---- out = res + g*o ;  d_o = g*dout, dg = sum dout*o ----------------------------------------------
@@ -327,7 +323,7 @@ template <typename T, int V_> struct GatedAddFwdOp : OpBase<T, V_> {
     for (int i = 0; i < V_; ++i) fr[i] = in[0][i] + st.g[i] * in[1][i];
     VecIO<T, V_>::store(out + e, fr);
   }
-  __device__ void write_part(long long, const float (&)[1][V_]) const {}
+  __device__ float* part(int) const { return nullptr; }
 };
 // SUM: also the per-part column sums of d_o (the bias gradient of the conv that produced o), saving a pass over d_o
 template <typename T, int V_, bool SUM> struct GatedAddBwdOp : OpBase<T, V_> {
@@ -349,10 +345,7 @@ template <typename T, int V_, bool SUM> struct GatedAddBwdOp : OpBase<T, V_> {
     }
     VecIO<T, V_>::store(d_o + e, fd);
   }
-  __device__ void write_part(long long e, const float (&sm)[SUM ? 2 : 1][V_]) const {
-    this->stc(dg + e, sm[0]);
-    if (SUM) this->stc(dsum + e, sm[SUM ? 1 : 0]);
-  }
+  __device__ float* part(int k) const { return k ? dsum : dg; }
 };
 
 template <class OP>
@@ -387,6 +380,13 @@ template <typename T> bool can_vec(int c, std::initializer_list<const void*> ptr
   } while (0)
 
 #define PL(...) std::initializer_list<const void*>{__VA_ARGS__}
+
+// GELU (every production config) gets kernels with the activation compiled in; the rest keep the run-time switch
+#define DISPATCH_ACT(act, ...)                                                      \
+  do {                                                                              \
+    if ((act) == UNET_ACT_GELU) { constexpr int ACT = UNET_ACT_GELU; __VA_ARGS__ }  \
+    else { constexpr int ACT = -1; __VA_ARGS__ }                                    \
+  } while (0)
 
 int check_dims(int n, int rows, int c, const char* what) {
   UNET_REQUIRE(n > 0 && rows > 0 && c > 0, "%s: non-positive dims n=%d rows=%d c=%d", what, n, rows, c);
@@ -892,13 +892,17 @@ extern "C" int unet_affine_act_fwd(int32_t dtype, const void* y, const float* a,
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (pool_part) {
     DISPATCH_ROWS(dtype, c, PL(y, z), {
-      AffineActFwdOp<T, V, true> op; op.y = (const T*)y; op.z = (T*)z; op.a = a; op.b = b; op.pool = pool_part; op.act = act;
-      return launch_rows(op, n, rows, c, st, "affine_act_fwd");
+      DISPATCH_ACT(act, {
+        AffineActFwdOp<T, V, true, ACT> op; op.y = (const T*)y; op.z = (T*)z; op.a = a; op.b = b; op.pool = pool_part; op.act = act;
+        return launch_rows(op, n, rows, c, st, "affine_act_fwd");
+      });
     });
   } else {
     DISPATCH_ROWS(dtype, c, PL(y, z), {
-      AffineActFwdOp<T, V, false> op; op.y = (const T*)y; op.z = (T*)z; op.a = a; op.b = b; op.pool = nullptr; op.act = act;
-      return launch_rows(op, n, rows, c, st, "affine_act_fwd");
+      DISPATCH_ACT(act, {
+        AffineActFwdOp<T, V, false, ACT> op; op.y = (const T*)y; op.z = (T*)z; op.a = a; op.b = b; op.pool = nullptr; op.act = act;
+        return launch_rows(op, n, rows, c, st, "affine_act_fwd");
+      });
     });
   }
   return 0;
@@ -911,9 +915,11 @@ extern "C" int unet_affine_act_bwd_reduce(int32_t dtype, const void* y, const vo
   UNET_REQUIRE(y && dz && a && b && g1_part && g2_part, "affine_act_bwd_reduce: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH_ROWS(dtype, c, PL(y, dz), {
-    AffineActBwdOp<T, V, false> op; op.y = (const T*)y; op.dz = (const T*)dz; op.dpool = dpool; op.a = a; op.b = b;
-    op.act = act; op.g1 = g1_part; op.g2 = g2_part; op.ca = op.cb = op.cc = nullptr; op.dy = nullptr; op.dysum = nullptr;
-    return launch_rows(op, n, rows, c, st, "affine_act_bwd_reduce");
+    DISPATCH_ACT(act, {
+      AffineActBwdOp<T, V, false, false, false, ACT> op; op.y = (const T*)y; op.dz = (const T*)dz; op.dpool = dpool; op.a = a; op.b = b;
+      op.act = act; op.g1 = g1_part; op.g2 = g2_part; op.ca = op.cb = op.cc = nullptr; op.dy = nullptr; op.dysum = nullptr;
+      return launch_rows(op, n, rows, c, st, "affine_act_bwd_reduce");
+    });
   });
   return 0;
 }
@@ -926,9 +932,11 @@ extern "C" int unet_affine_act_bwd_apply(int32_t dtype, const void* y, const voi
   UNET_REQUIRE(y && dz && a && b && ca && cb && cc && dy, "affine_act_bwd_apply: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH_ROWS(dtype, c, PL(y, dz, dy), {
-    AffineActBwdOp<T, V, true> op; op.y = (const T*)y; op.dz = (const T*)dz; op.dpool = dpool; op.a = a; op.b = b;
-    op.act = act; op.g1 = op.g2 = nullptr; op.ca = ca; op.cb = cb; op.cc = cc; op.dy = (T*)dy; op.dysum = nullptr;
-    return launch_rows(op, n, rows, c, st, "affine_act_bwd_apply");
+    DISPATCH_ACT(act, {
+      AffineActBwdOp<T, V, true, false, false, ACT> op; op.y = (const T*)y; op.dz = (const T*)dz; op.dpool = dpool; op.a = a; op.b = b;
+      op.act = act; op.g1 = op.g2 = nullptr; op.ca = ca; op.cb = cb; op.cc = cc; op.dy = (T*)dy; op.dysum = nullptr;
+      return launch_rows(op, n, rows, c, st, "affine_act_bwd_apply");
+    });
   });
   return 0;
 }
@@ -942,9 +950,11 @@ extern "C" int unet_affine_act_bwd_apply_sum(int32_t dtype, const void* y, const
   UNET_REQUIRE(y && dz && a && b && ca && cb && cc && dy, "affine_act_bwd_apply_sum: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH_ROWS(dtype, c, PL(y, dz, dy), {
-    AffineActBwdOp<T, V, true, true> op; op.y = (const T*)y; op.dz = (const T*)dz; op.dpool = dpool; op.a = a; op.b = b;
-    op.act = act; op.g1 = op.g2 = nullptr; op.ca = ca; op.cb = cb; op.cc = cc; op.dy = (T*)dy; op.dysum = dy_sum_part;
-    return launch_rows(op, n, rows, c, st, "affine_act_bwd_apply_sum");
+    DISPATCH_ACT(act, {
+      AffineActBwdOp<T, V, true, true, false, ACT> op; op.y = (const T*)y; op.dz = (const T*)dz; op.dpool = dpool; op.a = a; op.b = b;
+      op.act = act; op.g1 = op.g2 = nullptr; op.ca = ca; op.cb = cb; op.cc = cc; op.dy = (T*)dy; op.dysum = dy_sum_part;
+      return launch_rows(op, n, rows, c, st, "affine_act_bwd_apply_sum");
+    });
   });
   return 0;
 }
@@ -955,8 +965,10 @@ extern "C" int unet_affine_pool(int32_t dtype, const void* y, const float* a, co
   UNET_REQUIRE(y && a && b && pool_part, "affine_pool: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH_ROWS(dtype, c, PL(y), {
-    AffinePoolOp<T, V> op; op.y = (const T*)y; op.a = a; op.b = b; op.pool = pool_part; op.act = act;
-    return launch_rows(op, n, rows, c, st, "affine_pool");
+    DISPATCH_ACT(act, {
+      AffinePoolOp<T, V, ACT> op; op.y = (const T*)y; op.a = a; op.b = b; op.pool = pool_part; op.act = act;
+      return launch_rows(op, n, rows, c, st, "affine_pool");
+    });
   });
   return 0;
 }
@@ -967,8 +979,10 @@ extern "C" int unet_affine_act_scale_fwd(int32_t dtype, const void* y, const flo
   UNET_REQUIRE(y && a && b && s && z, "affine_act_scale_fwd: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH_ROWS(dtype, c, PL(y, z), {
-    AffineActScaleFwdOp<T, V> op; op.y = (const T*)y; op.z = (T*)z; op.a = a; op.b = b; op.sc = s; op.act = act;
-    return launch_rows(op, n, rows, c, st, "affine_act_scale_fwd");
+    DISPATCH_ACT(act, {
+      AffineActScaleFwdOp<T, V, ACT> op; op.y = (const T*)y; op.z = (T*)z; op.a = a; op.b = b; op.sc = s; op.act = act;
+      return launch_rows(op, n, rows, c, st, "affine_act_scale_fwd");
+    });
   });
   return 0;
 }
@@ -979,9 +993,11 @@ extern "C" int unet_affine_act_se_bwd_reduce(int32_t dtype, const void* y, const
   UNET_REQUIRE(y && dz && a && b && p_part, "affine_act_se_bwd_reduce: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH_ROWS(dtype, c, PL(y, dz), {
-    AffineActSEBwdReduceOp<T, V> op; op.y = (const T*)y; op.dz = (const T*)dz; op.a = a; op.b = b; op.act = act;
-    op.p = p_part; op.pstride = (long long)n * cdiv(rows, rows_per_part(rows)) * c;
-    return launch_rows(op, n, rows, c, st, "affine_act_se_bwd_reduce");
+    DISPATCH_ACT(act, {
+      AffineActSEBwdReduceOp<T, V, ACT> op; op.y = (const T*)y; op.dz = (const T*)dz; op.a = a; op.b = b; op.act = act;
+      op.p = p_part; op.pstride = (long long)n * cdiv(rows, rows_per_part(rows)) * c;
+      return launch_rows(op, n, rows, c, st, "affine_act_se_bwd_reduce");
+    });
   });
   return 0;
 }
@@ -1004,10 +1020,12 @@ extern "C" int unet_affine_act_se_bwd_apply(int32_t dtype, const void* y, const 
   UNET_REQUIRE(y && dz && s && a && b && ca && cb && cc && dy && dy_sum_part, "affine_act_se_bwd_apply: null pointer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH_ROWS(dtype, c, PL(y, dz, dy), {
-    AffineActBwdOp<T, V, true, true, true> op; op.y = (const T*)y; op.dz = (const T*)dz; op.dpool = dpool; op.sc = s;
-    op.a = a; op.b = b; op.act = act; op.g1 = op.g2 = nullptr; op.ca = ca; op.cb = cb; op.cc = cc; op.dy = (T*)dy;
-    op.dysum = dy_sum_part;
-    return launch_rows(op, n, rows, c, st, "affine_act_se_bwd_apply");
+    DISPATCH_ACT(act, {
+      AffineActBwdOp<T, V, true, true, true, ACT> op; op.y = (const T*)y; op.dz = (const T*)dz; op.dpool = dpool; op.sc = s;
+      op.a = a; op.b = b; op.act = act; op.g1 = op.g2 = nullptr; op.ca = ca; op.cb = cb; op.cc = cc; op.dy = (T*)dy;
+      op.dysum = dy_sum_part;
+      return launch_rows(op, n, rows, c, st, "affine_act_se_bwd_apply");
+    });
   });
   return 0;
 }
