@@ -48,6 +48,8 @@ def main():
             ("affine_act_scale_fwd", 2, lambda L: L.unet_affine_act_scale_fwd(0, P(y), P(a), P(b), 3, P(a), P(o1), n, rows, c, st)),
             ("se_bwd_reduce", 2, lambda L: L.unet_affine_act_se_bwd_reduce(0, P(y), P(dz), P(a), P(b), 3, P(p5), n, rows, c, st)),
             ("se_bwd_apply", 3, lambda L: L.unet_affine_act_se_bwd_apply(0, P(y), P(dz), P(b), P(a), P(a), P(b), 3, P(a), P(b), P(b), P(o1), P(p1), n, rows, c, st)),
+            ("film_softmax_fwd", 2, lambda L: L.unet_film_softmax_fwd(0, P(y), P(a), P(b), P(o1), n, rows, c, st)),
+            ("film_softmax_bwd+sum", 3, lambda L: L.unet_film_softmax_bwd(0, P(y), P(dz), P(a), P(b), P(o1), P(p1), P(p2), P(p5[0]), n, rows, c, st)),
             ("scale_fwd", 2, lambda L: L.unet_scale_fwd(0, P(y), P(a), P(o1), n, rows, c, st)),
             ("scale_bwd", 3, lambda L: L.unet_scale_bwd(0, P(y), P(dz), P(a), P(o1), P(p1), n, rows, c, st)),
             ("gated_add_fwd", 3, lambda L: L.unet_gated_add_fwd(0, P(y), P(dz), P(a), P(o1), n, rows, c, st)),

@@ -203,14 +203,28 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ float row16_max(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0xB1>{}));
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x4E>{}));
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x141>{}));
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x140>{}));
+  return v;
+}
+
+// all 64 lanes: four DPP steps inside the rows of 16, two cross-row exchanges (ds_bpermute)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = row16_max(v);
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
 

@@ -397,9 +397,15 @@ int check_dims(int n, int rows, int c, const char* what) {
 // ---------------------------------------------------------------------------------------------
 // FiLM channel softmax: one wave per row, lanes stride over channel vectors of 4.
 // ---------------------------------------------------------------------------------------------
+// rows a wave keeps in flight: the row is a dependent chain (load -> max -> exp -> sum -> scale -> store).  Measured
+// (scripts/ab_rows.py): four rows at C = 256 (one vector per lane) -6 %; two rows at C = 512 +2 %, so wider rows keep one;
+// the backward kernel with two rows at C = 256 ran 35 % slower (registers) and keeps one everywhere.
+template <int NV> struct FilmRows { static constexpr int U = NV <= 1 ? 4 : 1; };
+
 template <typename T, int V, int NV>
 __global__ __launch_bounds__(THREADS) void film_softmax_fwd_kernel(const T* q, const float* kk, const float* vv,
                                                                     T* h, int rows, int c) {
+  constexpr int U = FilmRows<NV>::U;
   const int n = blockIdx.y, part = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cv = c / V;
   float k[NV][V], v[NV][V];
@@ -415,38 +421,61 @@ __global__ __launch_bounds__(THREADS) void film_softmax_fwd_kernel(const T* q, c
   const int rpp = rows_per_part(rows);
   const int r_begin = part * rpp;
   const int r_end = rows < r_begin + rpp ? rows : r_begin + rpp;
-  for (int r = r_begin + wave; r < r_end; r += THREADS / 64) {
-    const long long base = ((long long)n * rows + r) * c;
-    float s[NV][V];
-    float mx = -INFINITY;
+  for (int r0 = r_begin + wave * U; r0 < r_end; r0 += (THREADS / 64) * U) {
+    float s[U][NV][V];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int cg = lane + 64 * i;
-      if (cg < cv) {
-        VecIO<T, V>::load(q + base + cg * V, s[i]);
+    for (int u = 0; u < U; ++u) {
+      const long long base = ((long long)n * rows + r0 + u) * c;
 #pragma unroll
-        for (int e = 0; e < V; ++e) { s[i][e] *= k[i][e]; mx = fmaxf(mx, s[i][e]); }
+      for (int i = 0; i < NV; ++i) {
+        const int cg = lane + 64 * i;
+        if (cg < cv && r0 + u < r_end) VecIO<T, V>::load(q + base + cg * V, s[u][i]);
+        else {
+#pragma unroll
+          for (int e = 0; e < V; ++e) s[u][i][e] = 0.f;
+        }
       }
     }
-    mx = wave_max(mx);
-    float sum = 0.f;
+    __builtin_amdgcn_sched_barrier(0);      // every row's loads above the arithmetic
+    float mx[U], sum[U];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int cg = lane + 64 * i;
-      if (cg < cv) {
+    for (int u = 0; u < U; ++u) {
+      mx[u] = -INFINITY;
 #pragma unroll
-        for (int e = 0; e < V; ++e) { s[i][e] = __expf(s[i][e] - mx); sum += s[i][e]; }
+      for (int i = 0; i < NV; ++i) {
+        const bool in = lane + 64 * i < cv;
+#pragma unroll
+        for (int e = 0; e < V; ++e) { s[u][i][e] = in ? s[u][i][e] * k[i][e] : -INFINITY; mx[u] = fmaxf(mx[u], s[u][i][e]); }
       }
     }
-    sum = wave_sum(sum);
-    const float inv = 1.f / sum;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int cg = lane + 64 * i;
-      if (cg < cv) {
+    for (int u = 0; u < U; ++u) mx[u] = wave_max(mx[u]);
 #pragma unroll
-        for (int e = 0; e < V; ++e) s[i][e] = s[i][e] * inv * v[i][e];
-        VecIO<T, V>::store(h + base + cg * V, s[i]);
+    for (int u = 0; u < U; ++u) {
+      sum[u] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          s[u][i][e] = __expf(s[u][i][e] - mx[u]);       // channels past the end: exp(-inf) = 0
+          sum[u] += s[u][i][e];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) sum[u] = wave_sum(sum[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r0 + u >= r_end) continue;          // wave-uniform
+      const float inv = 1.f / sum[u];
+      const long long base = ((long long)n * rows + r0 + u) * c;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int cg = lane + 64 * i;
+        if (cg < cv) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) s[u][i][e] = s[u][i][e] * inv * v[i][e];
+          VecIO<T, V>::store(h + base + cg * V, s[u][i]);
+        }
       }
     }
   }
@@ -458,6 +487,7 @@ __global__ __launch_bounds__(THREADS) void film_softmax_bwd_kernel(const T* q, c
                                                                     const float* vv, T* dq, float* dkk_part,
                                                                     float* dv_part, float* dq_sum_part, int rows, int c,
                                                                     int parts) {
+  constexpr int U = 1;
   __shared__ float red_s[SUM ? 3 : 2][THREADS / 64][64 * NV * V];
   const int n = blockIdx.y, part = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cv = c / V;
@@ -476,59 +506,77 @@ __global__ __launch_bounds__(THREADS) void film_softmax_bwd_kernel(const T* q, c
   const int rpp = rows_per_part(rows);
   const int r_begin = part * rpp;
   const int r_end = rows < r_begin + rpp ? rows : r_begin + rpp;
-  for (int r = r_begin + wave; r < r_end; r += THREADS / 64) {
-    const long long base = ((long long)n * rows + r) * c;
-    float s[NV][V], qv[NV][V], g[NV][V];
-    float mx = -INFINITY;
+  for (int r0 = r_begin + wave * U; r0 < r_end; r0 += (THREADS / 64) * U) {
+    float s[U][NV][V], qv[U][NV][V], g[U][NV][V];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int cg = lane + 64 * i;
-      if (cg < cv) {
-        VecIO<T, V>::load(q + base + cg * V, qv[i]);
-        VecIO<T, V>::load(dh + base + cg * V, g[i]);
+    for (int u = 0; u < U; ++u) {
+      const long long base = ((long long)n * rows + r0 + u) * c;
 #pragma unroll
-        for (int e = 0; e < V; ++e) { s[i][e] = qv[i][e] * k[i][e]; mx = fmaxf(mx, s[i][e]); }
-      }
-    }
-    mx = wave_max(mx);
-    float sum = 0.f;
+      for (int i = 0; i < NV; ++i) {
+        const int cg = lane + 64 * i;
+        if (cg < cv && r0 + u < r_end) {
+          VecIO<T, V>::load(q + base + cg * V, qv[u][i]);
+          VecIO<T, V>::load(dh + base + cg * V, g[u][i]);
+        } else {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int cg = lane + 64 * i;
-      if (cg < cv) {
-#pragma unroll
-        for (int e = 0; e < V; ++e) { s[i][e] = __expf(s[i][e] - mx); sum += s[i][e]; }
-      }
-    }
-    sum = wave_sum(sum);
-    const float inv = 1.f / sum;
-    float dot = 0.f;  // sum_c a * da,  da = dh * v
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int cg = lane + 64 * i;
-      if (cg < cv) {
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-          s[i][e] *= inv;                       // a
-          av[i][e] += g[i][e] * s[i][e];        // dv += dh * a
-          g[i][e] *= v[i][e];                   // da
-          dot += s[i][e] * g[i][e];
+          for (int e = 0; e < V; ++e) { qv[u][i][e] = 0.f; g[u][i][e] = 0.f; }   // a row past the end adds zeros
         }
       }
     }
-    dot = wave_sum(dot);
+    __builtin_amdgcn_sched_barrier(0);      // every row's loads above the arithmetic
+    float mx[U], sum[U], dot[U];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int cg = lane + 64 * i;
-      if (cg < cv) {
+    for (int u = 0; u < U; ++u) {
+      mx[u] = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const bool in = lane + 64 * i < cv;
+#pragma unroll
+        for (int e = 0; e < V; ++e) { s[u][i][e] = in ? qv[u][i][e] * k[i][e] : -INFINITY; mx[u] = fmaxf(mx[u], s[u][i][e]); }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) mx[u] = wave_max(mx[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      sum[u] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < V; ++e) { s[u][i][e] = __expf(s[u][i][e] - mx[u]); sum[u] += s[u][i][e]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) sum[u] = wave_sum(sum[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float inv = 1.f / sum[u];
+      dot[u] = 0.f;  // sum_c a * da,  da = dh * v
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          const float ds = s[i][e] * (g[i][e] - dot);  // d(q*kk)
-          akk[i][e] += ds * qv[i][e];
-          g[i][e] = ds * k[i][e];
-          if (SUM) adq[SUM ? i : 0][e] += g[i][e];
+          s[u][i][e] *= inv;                             // a
+          av[i][e] += g[u][i][e] * s[u][i][e];           // dv += dh * a
+          g[u][i][e] *= v[i][e];                         // da
+          dot[u] += s[u][i][e] * g[u][i][e];
         }
-        VecIO<T, V>::store(dq + base + cg * V, g[i]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) dot[u] = wave_sum(dot[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long base = ((long long)n * rows + r0 + u) * c;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int cg = lane + 64 * i;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const float ds = s[u][i][e] * (g[u][i][e] - dot[u]);  // d(q*kk)
+          akk[i][e] += ds * qv[u][i][e];
+          g[u][i][e] = ds * k[i][e];
+          if (SUM) adq[SUM ? i : 0][e] += g[u][i][e];
+        }
+        if (cg < cv && r0 + u < r_end) VecIO<T, V>::store(dq + base + cg * V, g[u][i]);
       }
     }
   }
