@@ -45,13 +45,32 @@ __global__ __launch_bounds__(SL_THREADS) void small_linear_fwd_kernel(const Smal
   const int k_end = min(q.n_in, (kz + 1) * SL_KS);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int k0 = kz * SL_KS; k0 < k_end; k0 += SL_T) {
-    for (int i = t; i < SL_T * SL_T; i += SL_THREADS) {
-      const int r = i >> 6, k = i & 63;
-      xs[r * SL_LD + k] = (n0 + r < b.n && k0 + k < k_end) ? q.x[(long long)(n0 + r) * q.n_in + k0 + k] : 0.f;
+    // all 20 loads of the chunk issued back to back (clamped addresses, masked afterwards): as conditional loads in
+    // a loop they ran one after the other, ~1 us each, and every launch took 19 us whatever its size
+    float xr[SL_T * SL_T / SL_THREADS], wr[SL_TO * SL_T / SL_THREADS];
+#pragma unroll
+    for (int j = 0; j < SL_T * SL_T / SL_THREADS; ++j) {
+      const int i = t + j * SL_THREADS, r = i >> 6, k = i & 63;
+      const bool ok = n0 + r < b.n && k0 + k < k_end;
+      xr[j] = q.x[ok ? (long long)(n0 + r) * q.n_in + k0 + k : 0];
+      xr[j] = ok ? xr[j] : 0.f;
     }
-    for (int i = t; i < SL_TO * SL_T; i += SL_THREADS) {
-      const int r = i >> 6, k = i & 63;
-      ws[r * SL_LD + k] = (o0 + r < q.n_out && k0 + k < k_end) ? q.w[(long long)(o0 + r) * q.n_in + k0 + k] : 0.f;
+#pragma unroll
+    for (int j = 0; j < SL_TO * SL_T / SL_THREADS; ++j) {
+      const int i = t + j * SL_THREADS, r = i >> 6, k = i & 63;
+      const bool ok = o0 + r < q.n_out && k0 + k < k_end;
+      wr[j] = q.w[ok ? (long long)(o0 + r) * q.n_in + k0 + k : 0];
+      wr[j] = ok ? wr[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < SL_T * SL_T / SL_THREADS; ++j) {
+      const int i = t + j * SL_THREADS;
+      xs[(i >> 6) * SL_LD + (i & 63)] = xr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < SL_TO * SL_T / SL_THREADS; ++j) {
+      const int i = t + j * SL_THREADS;
+      ws[(i >> 6) * SL_LD + (i & 63)] = wr[j];
     }
     __syncthreads();
 #pragma unroll 8
@@ -108,25 +127,53 @@ __global__ __launch_bounds__(SL_THREADS) void small_linear_bwd_kernel(const Smal
   if (k0 >= q.n_in) return;
   {
     float dw[4] = {0.f, 0.f, 0.f, 0.f};    // dW[o0 + g4*4 + u][k0 + il]
-    for (int i = t; i < SL_TO * SL_T; i += SL_THREADS) {
-      const int r = i >> 6, k = i & 63;
-      ws[r * SL_LD + k] = (o0 + r < q.n_out && k0 + k < q.n_in) ? q.w[(long long)(o0 + r) * q.n_in + k0 + k] : 0.f;
-    }
-    for (int n0 = 0; n0 < b.n; n0 += SL_T) {
-      for (int i = t; i < SL_T * SL_TO; i += SL_THREADS) {
-        const int r = i >> 4, k = i & 15;          // r: window, k: output of the tile
-        float d = 0.f;
-        if (n0 + r < b.n && o0 + k < q.n_out) {
-          const long long e = (long long)(n0 + r) * q.n_out + o0 + k;
-          d = q.dy[e] * q.scale;
-          if (q.act == UNET_SMALL_GELU) d *= act_bwd(UNET_ACT_GELU, q.pre[e]);
-          else if (q.act == UNET_SMALL_SIGMOID) { const float s = q.y[e]; d *= s * (1.f - s); }
-        }
-        ds[r * DLD + k] = d;
+    {
+      float wr[SL_TO * SL_T / SL_THREADS];
+#pragma unroll
+      for (int j = 0; j < SL_TO * SL_T / SL_THREADS; ++j) {
+        const int i = t + j * SL_THREADS, r = i >> 6, k = i & 63;
+        const bool ok = o0 + r < q.n_out && k0 + k < q.n_in;
+        wr[j] = q.w[ok ? (long long)(o0 + r) * q.n_in + k0 + k : 0];
+        wr[j] = ok ? wr[j] : 0.f;
       }
-      for (int i = t; i < SL_T * SL_T; i += SL_THREADS) {
-        const int r = i >> 6, k = i & 63;
-        xs[r * SL_LD + k] = (n0 + r < b.n && k0 + k < q.n_in) ? q.x[(long long)(n0 + r) * q.n_in + k0 + k] : 0.f;
+#pragma unroll
+      for (int j = 0; j < SL_TO * SL_T / SL_THREADS; ++j) {
+        const int i = t + j * SL_THREADS;
+        ws[(i >> 6) * SL_LD + (i & 63)] = wr[j];
+      }
+    }
+    const float* aux = q.act == UNET_SMALL_GELU ? q.pre : q.y;      // what the activation's derivative is taken from
+    for (int n0 = 0; n0 < b.n; n0 += SL_T) {
+      // loads first (clamped addresses), arithmetic and LDS writes after: see the forward kernel
+      float dr[SL_T * SL_TO / SL_THREADS], ar[SL_T * SL_TO / SL_THREADS], xr[SL_T * SL_T / SL_THREADS];
+#pragma unroll
+      for (int j = 0; j < SL_T * SL_TO / SL_THREADS; ++j) {
+        const int i = t + j * SL_THREADS, r = i >> 4, k = i & 15;          // r: window, k: output of the tile
+        const bool ok = n0 + r < b.n && o0 + k < q.n_out;
+        const long long e = ok ? (long long)(n0 + r) * q.n_out + o0 + k : 0;
+        dr[j] = q.dy[e];
+        ar[j] = q.act != UNET_SMALL_NONE ? aux[e] : 0.f;
+        dr[j] = ok ? dr[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < SL_T * SL_T / SL_THREADS; ++j) {
+        const int i = t + j * SL_THREADS, r = i >> 6, k = i & 63;
+        const bool ok = n0 + r < b.n && k0 + k < q.n_in;
+        xr[j] = q.x[ok ? (long long)(n0 + r) * q.n_in + k0 + k : 0];
+        xr[j] = ok ? xr[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < SL_T * SL_TO / SL_THREADS; ++j) {
+        const int i = t + j * SL_THREADS;
+        float d = dr[j] * q.scale;
+        if (q.act == UNET_SMALL_GELU) d *= act_bwd(UNET_ACT_GELU, ar[j]);
+        else if (q.act == UNET_SMALL_SIGMOID) d *= ar[j] * (1.f - ar[j]);
+        ds[(i >> 4) * DLD + (i & 15)] = d;
+      }
+#pragma unroll
+      for (int j = 0; j < SL_T * SL_T / SL_THREADS; ++j) {
+        const int i = t + j * SL_THREADS;
+        xs[(i >> 6) * SL_LD + (i & 63)] = xr[j];
       }
       __syncthreads();
       if (k0 == 0 && t < SL_TO) {
