@@ -832,9 +832,12 @@ int check_geometry(const char* what, int n, int l, int c, int nh, int nb) {
 extern "C" int unet_cfc_attn_fwd(int32_t dtype, const void* q, const void* k, const void* v, const float* coupling,
                                  int32_t n, int32_t l, int32_t c, int32_t n_heads, int32_t n_bands, float scale, void* out,
                                  void* o_pairs, float* lse, void* stream) {
-  UNET_REQUIRE(dtype == UNET_BF16, "cfc_attn_fwd: bf16 only (dtype %d)", dtype);
+  UNET_REQUIRE(dtype == UNET_BF16 || dtype == UNET_F32, "cfc_attn_fwd: bad dtype %d", dtype);
   UNET_REQUIRE(q && k && v && coupling && out, "cfc_attn_fwd: null pointer");
   UNET_REQUIRE(o_pairs || !lse, "cfc_attn_fwd: lse without o_pairs");
+  if (dtype == UNET_F32)      // exact-fp32 kernels (csrc/attn_f32.hip)
+    return unet_cfc_attn_fwd_f32(q, k, v, coupling, n, l, c, n_heads, n_bands, scale, out, o_pairs, lse,
+                                 static_cast<hipStream_t>(stream));
   UNET_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out) && aligned16(o_pairs),
                "cfc_attn_fwd: pointers must be 16-byte aligned");
   if (check_geometry("cfc_attn_fwd", n, l, c, n_heads, n_bands)) return -1;
@@ -860,9 +863,12 @@ extern "C" int unet_cfc_attn_bwd(int32_t dtype, const void* q, const void* k, co
                                  const void* o_pairs, const float* lse, const void* dout, int32_t n, int32_t l, int32_t c,
                                  int32_t n_heads, int32_t n_bands, float scale, void* dq, void* dk, void* dv,
                                  float* dcoupling_part, float* delta, void* stream) {
-  UNET_REQUIRE(dtype == UNET_BF16, "cfc_attn_bwd: bf16 only (dtype %d)", dtype);
+  UNET_REQUIRE(dtype == UNET_BF16 || dtype == UNET_F32, "cfc_attn_bwd: bad dtype %d", dtype);
   UNET_REQUIRE(q && k && v && coupling && o_pairs && lse && dout && dq && dk && dv && dcoupling_part && delta,
                "cfc_attn_bwd: null pointer");
+  if (dtype == UNET_F32)
+    return unet_cfc_attn_bwd_f32(q, k, v, coupling, o_pairs, lse, dout, n, l, c, n_heads, n_bands, scale, dq, dk, dv,
+                                 dcoupling_part, delta, static_cast<hipStream_t>(stream));
   UNET_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o_pairs) && aligned16(dout) && aligned16(dq) &&
                    aligned16(dk) && aligned16(dv),
                "cfc_attn_bwd: pointers must be 16-byte aligned");

@@ -16,6 +16,13 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
+// ---- fp32 band-pair attention (attn_f32.hip), reached through the extern "C" entry points of attn.hip ---------
+int unet_cfc_attn_fwd_f32(const void* q, const void* k, const void* v, const float* coupling, int n, int l, int c, int n_heads,
+                          int n_bands, float scale, void* out, void* o_pairs, float* lse, hipStream_t st);
+int unet_cfc_attn_bwd_f32(const void* q, const void* k, const void* v, const float* coupling, const void* o_pairs,
+                          const float* lse, const void* dout, int n, int l, int c, int n_heads, int n_bands, float scale,
+                          void* dq, void* dk, void* dv, float* dcoupling_part, float* delta, hipStream_t st);
+
 // ---- error plumbing (error.cpp) -------------------------------------------------------------
 void unet_set_error(const char* fmt, ...);
 #define UNET_REQUIRE(cond, ...)            \

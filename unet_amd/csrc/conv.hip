@@ -797,13 +797,17 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const PackK p) {
     v.u = u32x4{0u, 0u, 0u, 0u};
     if (r < p.rows) {
       const float* src = p.w + (long long)p.tap_src[tap] * p.ts + (long long)(p.row_lo + r) * p.rs;
+      float f[EPC];
 #pragma unroll
-      for (int k = 0; k < EPC; ++k) {
+      for (int k = 0; k < EPC; ++k) {       // the EPC loads issued together (clamped address, masked afterwards)
         int kk, col = -1;
         if (kc < p.kc1) { kk = kc * KC + c * EPC + k; if (kk < p.c1) col = p.col_lo + kk; }
         else { kk = (kc - p.kc1) * KC + c * EPC + k; if (kk < p.c2) col = p.col_lo + p.c1 + kk; }
-        if (col >= 0) v.e[k] = from_f32<T>(src[(long long)col * p.cs]);
+        f[k] = src[col >= 0 ? (long long)col * p.cs : 0];
+        f[k] = col >= 0 ? f[k] : 0.f;
       }
+#pragma unroll
+      for (int k = 0; k < EPC; ++k) v.e[k] = from_f32<T>(f[k]);
     }
     *reinterpret_cast<u32x4*>(p.out + idx * 16) = v.u;
   }
@@ -1225,8 +1229,26 @@ __global__ __launch_bounds__(THREADS, 2) void conv_wgrad2_kernel(const Wg2K p) {
   if (two) store(acc1, p.g_tapb[grp]);
 }
 
+// out = sum of the split-K slabs, in slab order (deterministic).  16 bytes per lane and eight slabs' loads in flight
+// per thread: as one scalar load per slab in a run-time loop the sum of a 1x1 conv's 32 slabs was 32 dependent
+// memory round trips (16 us for 256 KiB of output).
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, float* out, long long count, int splits) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+  const bool vec = !(count & 3) && !(reinterpret_cast<uintptr_t>(slab) & 15) && !(reinterpret_cast<uintptr_t>(out) & 15);
+  const long long c4 = vec ? count >> 2 : 0;               // float4 columns (count is a multiple of 4 in every config)
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < c4; i += (long long)gridDim.x * 256) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= splits; k += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(slab + (long long)(k + u) * count + 4 * i);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(slab + (long long)k * count + 4 * i);
+    *reinterpret_cast<f32x4*>(out + 4 * i) = s;
+  }
+  for (long long i = 4 * c4 + (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += slab[k * count + i];
     out[i] = s;
@@ -1741,7 +1763,8 @@ int wgrad_impl(const UnetConvDesc* d, const void* x1, const void* x2, const void
     UNET_REQUIRE(blocks < (1ll << 31), "conv_wgrad: grid too large");
     hipLaunchKernelGGL(conv_wgrad2_kernel, dim3((unsigned)blocks), dim3(THREADS), 2 * WG2_STAGE, st, k);
     UNET_LAUNCH_CHECK("conv_wgrad2");
-    int rb = (int)((count + 255) / 256 > 4096 ? 4096 : (count + 255) / 256);
+    const long long cols = (count & 3) ? count : count >> 2;
+    int rb = (int)((cols + 255) / 256 > 4096 ? 4096 : (cols + 255) / 256);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, st, k.slab, dw, count, splits);
     UNET_LAUNCH_CHECK("slab_reduce");
     return 0;

@@ -151,9 +151,9 @@ def _norm_act(y: Tensor, norm: nn.Module, act_id: int, want_pool: bool, se=None)
 # blocks (parameter layout = the reference's; compute = HIP ops)
 # ---------------------------------------------------------------------------------------------
 class SelfAttention1D(nn.Module):
-    """models.py:75-97.  1x1 projections on the HIP conv kernel; in bf16 the attention itself runs on the flash
-    kernels of csrc/attn.hip (query/key width a multiple of 8, i.e. channels >= 64); fp32 parity runs and narrower
-    layers evaluate softmax(q k^T) v with torch."""
+    """models.py:75-97.  1x1 projections on the HIP conv kernel; the attention itself runs on the flash kernels of
+    csrc/attn.hip (bf16, query/key width a multiple of 8, i.e. channels >= 64) or csrc/attn_f32.hip (fp32, a multiple
+    of 4, i.e. channels >= 32); only narrower layers evaluate softmax(q k^T) v with torch."""
 
     def __init__(self, channels: int, reduction: int = 8):
         super().__init__()
@@ -171,7 +171,7 @@ class SelfAttention1D(nn.Module):
         k = ops.conv(x, self.key.weight.permute(2, 0, 1), self.key.bias, g1, l)
         v = ops.conv(x, self.value.weight.permute(2, 0, 1), self.value.bias, g1, l)
         dq, rep = q.shape[2], self.channels // q.shape[2]
-        if self.use_flash and x.dtype == torch.bfloat16 and dq % 8 == 0 and dq <= 256 and rep * dq == self.channels:
+        if self.use_flash and dq % (8 if x.dtype == torch.bfloat16 else 4) == 0 and dq <= 256 and rep * dq == self.channels:
             # flash kernel of csrc/attn.hip (one band, no coupling, scale 1): the value channels are split into
             # `rep` heads of dq channels that all see the same scores, so q and k are tiled across the heads;
             # no [N, L, L] score tensor, one launch forward, three backward
@@ -189,11 +189,12 @@ class SelfAttention1D(nn.Module):
 def _band_pair_attention(q: Tensor, k: Tensor, v: Tensor, coupling: Tensor, n_heads: int, scale: float) -> Tensor:
     """q, k, v: [nb, M, l, C] stacks of the per-band projections -> [M, l, nb*C]:
     out[:, :, i*C + h*hd + d] = sum_j coupling[i, j] * softmax(q_i k_j^T * scale) v_j   (models.py:431-462 / 191-216).
-    bf16: ONE launch of the band-pair flash kernel (csrc/attn.hip; three launches backward).  fp32 (parity runs) and
-    head sizes the kernel does not take: the same products with ``scaled_dot_product_attention``."""
+    ONE launch of the band-pair flash kernel (bf16: csrc/attn.hip, MFMA 32x32x16; fp32: csrc/attn_f32.hip, exact fp32
+    MFMA 16x16x4; three launches backward).  Head sizes the kernels do not take: the same products with
+    ``scaled_dot_product_attention``."""
     nb, m, l, c = q.shape
     hd = c // n_heads
-    if q.dtype == torch.bfloat16 and hd % 8 == 0 and hd <= 256:
+    if hd % (8 if q.dtype == torch.bfloat16 else 4) == 0 and hd <= 256:
         return ops.cfc_attention(q.contiguous(), k.contiguous(), v.contiguous(), coupling, n_heads, scale)
     sp = lambda z: z.reshape(nb, m, l, n_heads, hd).transpose(2, 3)                    # [nb, M, heads, l, hd]
     qs, ks, vs = sp(q), sp(k), sp(v)

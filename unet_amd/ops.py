@@ -1163,15 +1163,17 @@ def cfc_attn_forward_raw(q: Tensor, k: Tensor, v: Tensor, coupling: Tensor, n_he
     for t in (q, k, v, coupling):
         _need_cuda(t)
     nb, n, l, c = q.shape
-    if q.dtype != torch.bfloat16 or not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
-        raise TypeError("cfc attention takes contiguous bfloat16 [nb, N, L, C] stacks")
+    if q.dtype not in (torch.bfloat16, torch.float32) or k.dtype != q.dtype or v.dtype != q.dtype or \
+            not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
+        raise TypeError("cfc attention takes contiguous [nb, N, L, C] stacks, all bfloat16 (MFMA flash kernels) or all "
+                        "float32 (exact-fp32 kernels)")
     coupling = coupling.float().contiguous()
     out = torch.empty((n, l, nb * c), dtype=q.dtype, device=q.device)
     # the pair outputs are stored also when nothing is kept for backward: the kernel variant that sums them in
     # registers instead is slower (see include/unet_hip.h) and rounds differently from the training path
     o_pairs = torch.empty((nb, nb, n, l, c), dtype=q.dtype, device=q.device)
     lse = torch.empty((nb, nb, n, n_heads, l), dtype=torch.float32, device=q.device) if keep else None
-    check(_lib.load().unet_cfc_attn_fwd(_lib.BF16, _p(q), _p(k), _p(v), _p(coupling), n, l, c, n_heads, nb, float(scale), _p(out),
+    check(_lib.load().unet_cfc_attn_fwd(_dt(q), _p(q), _p(k), _p(v), _p(coupling), n, l, c, n_heads, nb, float(scale), _p(out),
                                   _p(o_pairs), _p(lse), _stream()), "unet_cfc_attn_fwd")
     return out, o_pairs, lse
 
@@ -1198,14 +1200,16 @@ class CfcAttnFn(torch.autograd.Function):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         parts = torch.empty(lib.unet_cfc_attn_bwd_partials(n, l, nb), dtype=torch.float32, device=q.device).view(nb * nb, -1)
         delta = torch.empty_like(lse)
-        check(lib.unet_cfc_attn_bwd(_lib.BF16, _p(q), _p(k), _p(v), _p(coupling), _p(o_pairs), _p(lse), _p(dout), n, l, c,
+        if dout.dtype != q.dtype:
+            dout = dout.to(q.dtype)
+        check(lib.unet_cfc_attn_bwd(_dt(q), _p(q), _p(k), _p(v), _p(coupling), _p(o_pairs), _p(lse), _p(dout), n, l, c,
                                     ctx.n_heads, nb, float(ctx.scale), _p(dq), _p(dk), _p(dv), _p(parts), _p(delta),
                                     _stream()), "unet_cfc_attn_bwd")
         return dq, dk, dv, parts.sum(dim=1).view(nb, nb), None, None
 
 
 def cfc_attention(q: Tensor, k: Tensor, v: Tensor, coupling: Tensor, n_heads: int, scale: float) -> Tensor:
-    """q, k, v: [nb, N, L, C] bf16 stacks of the per-band projections; coupling: [nb, nb] softmaxed weights."""
+    """q, k, v: [nb, N, L, C] bf16 or fp32 stacks of the per-band projections; coupling: [nb, nb] softmaxed weights."""
     return CfcAttnFn.apply(q, k, v, coupling, n_heads, scale)
 
 
