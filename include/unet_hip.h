@@ -255,6 +255,21 @@ int unet_merge_taps_bwd(const float* const* w_branch_host, const float* sw, int3
                         int32_t ci, const int32_t* tap_index_host, int32_t n_taps, const float* dw_eff,
                         float* const* dw_branch_host, float* dsw_part, void* stream);
 
+/* The whole weight algebra of MultiScaleDilatedConv1d.forward (models.py:752-759) in one launch forward and two
+ * backward: w_eff as above, b_eff[co] = sum_b s[b] * bias_b[co], with s = softmax(sw) when `softmax` != 0 (sw = the
+ * raw scale_weights parameter) and s = sw otherwise.  sw_out (nullable): the branch weights s that were used, which
+ * is what the backward call takes as `sw`.  bwd: additionally d bias_b = s[b] * db_eff, and dsw (nullable) =
+ * the sum of dsw_part (incl. the bias term) taken back through the softmax when `softmax` != 0. */
+int unet_merge_branches_fwd(const float* const* w_branch_host, const float* const* bias_branch_host, const float* sw,
+                            int32_t softmax, int32_t n_branch, int32_t k, int32_t co, int32_t ci,
+                            const int32_t* tap_index_host, int32_t n_taps, float* w_eff, float* b_eff, float* sw_out,
+                            void* stream);
+int unet_merge_branches_bwd(const float* const* w_branch_host, const float* const* bias_branch_host, const float* sw,
+                            int32_t softmax, int32_t n_branch, int32_t k, int32_t co, int32_t ci,
+                            const int32_t* tap_index_host, int32_t n_taps, const float* dw_eff, const float* db_eff,
+                            float* const* dw_branch_host, float* const* dbias_branch_host, float* dsw_part, float* dsw,
+                            void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Per-window vector algebra (csrc/small.hip): the Linear layers on [windows][channels] vectors -- FiLM's k_proj /
  * v_proj / gate (models.py:493-494, 497-500, 506-509) and the SqueezeExcitation MLP (models.py:650-655, 660-661).

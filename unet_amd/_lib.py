@@ -90,6 +90,10 @@ _SIGNATURES = {
     "unet_merge_taps_fwd": (C.c_int, [C.POINTER(_vp), _vp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _vp, _vp]),
     "unet_merge_taps_bwd": (C.c_int, [C.POINTER(_vp), _vp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _vp,
                                       C.POINTER(_vp), _vp, _vp]),
+    "unet_merge_branches_fwd": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32),
+                                          _i32, _vp, _vp, _vp, _vp]),
+    "unet_merge_branches_bwd": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_i32),
+                                          _i32, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _vp]),
     "unet_small_linear_fwd": (C.c_int, [C.POINTER(SmallLinear), _i32, _i32, _vp]),
     "unet_small_linear_bwd": (C.c_int, [C.POINTER(SmallLinear), _i32, _i32, _vp]),
     "unet_small_linear_tiles": (_i32, [_i32]),

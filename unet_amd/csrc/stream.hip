@@ -1231,19 +1231,52 @@ constexpr int MT_MAXB = 8, MT_MAXK = 9;
 struct MergeK {
   const float* w[MT_MAXB];
   float* dw[MT_MAXB];
+  const float* bias[MT_MAXB];   // optional: branch biases [co]  (b_eff = sum_b sw[b] * bias_b)
+  float* dbias[MT_MAXB];
   int tap[MT_MAXB * MT_MAXK];
-  int nb, k, n_taps;
+  int nb, k, n_taps, co;
+  int softmax;                  // sw arrives raw: the kernel applies softmax over the branches itself
   long long pairs;   // co * ci
 };
+
+// the branch weights: softmax(raw) over <= 8 values, or the values as they are
+__device__ __forceinline__ void branch_weights(const MergeK& p, const float* sw, float (&s)[MT_MAXB]) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int b = 0; b < MT_MAXB; ++b) { s[b] = b < p.nb ? sw[b] : -INFINITY; m = fmaxf(m, s[b]); }
+  if (p.softmax) {
+    float sum = 0.f;
+#pragma unroll
+    for (int b = 0; b < MT_MAXB; ++b) { s[b] = b < p.nb ? expf(s[b] - m) : 0.f; sum += s[b]; }
+#pragma unroll
+    for (int b = 0; b < MT_MAXB; ++b) s[b] /= sum;
+  }
+}
 
 // A block owns 256 (co, ci) pairs.  Branch weights are [co][ci][k]: the block's 256 * k floats of a branch are one
 // contiguous run, moved to and from LDS with unit-stride accesses; the thread of a pair then works on its k values
 // there (stride k floats: conflict-free for the odd kernel sizes in use).  As per-thread strided global loads in
 // run-time loops plus a 32-way select chain per tap the two kernels took 37 / 35 us per conv.
-__global__ __launch_bounds__(256) void merge_taps_fwd_kernel(MergeK p, const float* sw, float* w_eff) {
+__global__ __launch_bounds__(256) void merge_taps_fwd_kernel(MergeK p, const float* sw, float* w_eff, float* b_eff,
+                                                             float* sw_out) {
   __shared__ float wt[256 * MT_MAXK];
   __shared__ float acc[UNET_MAX_TAPS * 256];
   const int tid = threadIdx.x;
+  float sb[MT_MAXB];
+  branch_weights(p, sw, sb);
+  if (blockIdx.x == 0) {                   // the few per-channel / per-branch by-products ride on the first block
+    if (sw_out && tid < p.nb) {
+#pragma unroll
+      for (int b = 0; b < MT_MAXB; ++b) if (b == tid) sw_out[b] = sb[b];
+    }
+    if (b_eff)
+      for (int c = tid; c < p.co; c += 256) {
+        float v = 0.f;
+#pragma unroll
+        for (int b = 0; b < MT_MAXB; ++b) if (b < p.nb) v += sb[b] * p.bias[b][c];
+        b_eff[c] = v;
+      }
+  }
   const long long i0 = (long long)blockIdx.x * 256;
   const int cnt = (int)(p.pairs - i0 < 256 ? p.pairs - i0 : 256);     // pairs of this block
   for (int t = 0; t < p.n_taps; ++t) acc[t * 256 + tid] = 0.f;
@@ -1262,14 +1295,19 @@ __global__ __launch_bounds__(256) void merge_taps_fwd_kernel(MergeK p, const flo
     for (int j = 0; j < MT_MAXK; ++j)
       if (j < p.k) wt[j * 256 + tid] = r[j];
     __syncthreads();
-    const float s = sw[b];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MT_MAXB; ++j) if (j == b) s = sb[j];
     for (int k = 0; k < p.k; ++k) acc[p.tap[b * p.k + k] * 256 + tid] += s * wt[tid * p.k + k];   // own column only
   }
   if (tid < cnt)
     for (int t = 0; t < p.n_taps; ++t) w_eff[(long long)t * p.pairs + i0 + tid] = acc[t * 256 + tid];
 }
 
-__global__ __launch_bounds__(256) void merge_taps_bwd_kernel(MergeK p, const float* sw, const float* dw_eff, float* dsw_part) {
+// sw: the (softmaxed) branch weights the forward pass used.  db_eff (optional): gradient of b_eff; block 0 then also
+// writes d bias_b = sw[b] * db_eff and adds <db_eff, bias_b> to its partial of d sw[b].
+__global__ __launch_bounds__(256) void merge_taps_bwd_kernel(MergeK p, const float* sw, const float* dw_eff, float* dsw_part,
+                                                             const float* db_eff) {
   __shared__ float red[MT_MAXB][256 / 64];
   __shared__ float wt[256 * MT_MAXK], gt[256 * MT_MAXK];
   const int tid = threadIdx.x;
@@ -1309,6 +1347,12 @@ __global__ __launch_bounds__(256) void merge_taps_bwd_kernel(MergeK p, const flo
       const int e = j * 256 + tid;
       if (j < p.k && e < cnt * p.k) dwb[e] = gt[e];
     }
+    if (db_eff && blockIdx.x == 0)
+      for (int c = tid; c < p.co; c += 256) {
+        const float g = db_eff[c];
+        p.dbias[b][c] = s * g;
+        dot += g * p.bias[b][c];
+      }
     dot = wave_sum(dot);
     if ((tid & 63) == 0) red[b][tid >> 6] = dot;
   }
@@ -1317,12 +1361,38 @@ __global__ __launch_bounds__(256) void merge_taps_bwd_kernel(MergeK p, const flo
     dsw_part[(long long)blockIdx.x * p.nb + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
 }
 
+// d sw[b] = sum of the per-block partials (fp64), then through the branch softmax: d raw = s o (d sw - <s, d sw>)
+__global__ __launch_bounds__(256) void merge_taps_finish_kernel(const float* dsw_part, int parts, int nb, const float* sw,
+                                                                float* d_out, int softmax) {
+  __shared__ double red[MT_MAXB][256];
+  const int tid = threadIdx.x;
+  for (int b = 0; b < nb; ++b) {
+    double a = 0.0;
+    for (int r = tid; r < parts; r += 256) a += dsw_part[(long long)r * nb + b];
+    red[b][tid] = a;
+  }
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o)
+      for (int b = 0; b < nb; ++b) red[b][tid] += red[b][tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double dot = 0.0;
+    for (int b = 0; b < nb; ++b) dot += (double)sw[b] * red[b][0];
+    for (int b = 0; b < nb; ++b) d_out[b] = (float)(softmax ? (double)sw[b] * (red[b][0] - dot) : red[b][0]);
+  }
+}
+
 int merge_setup(MergeK& p, const float* const* w_host, float* const* dw_host, int nb, int k, int co, int ci,
                 const int32_t* tap_host, int n_taps) {
   UNET_REQUIRE(nb > 0 && nb <= MT_MAXB && k > 0 && k <= MT_MAXK && co > 0 && ci > 0, "merge_taps: bad sizes nb=%d k=%d", nb, k);
   UNET_REQUIRE(n_taps > 0 && n_taps <= UNET_MAX_TAPS && tap_host && w_host, "merge_taps: bad tap table");
-  p.nb = nb; p.k = k; p.n_taps = n_taps; p.pairs = (long long)co * ci;
-  for (int b = 0; b < MT_MAXB; ++b) { p.w[b] = b < nb ? w_host[b] : nullptr; p.dw[b] = (dw_host && b < nb) ? dw_host[b] : nullptr; }
+  p.nb = nb; p.k = k; p.n_taps = n_taps; p.co = co; p.softmax = 0; p.pairs = (long long)co * ci;
+  for (int b = 0; b < MT_MAXB; ++b) {
+    p.w[b] = b < nb ? w_host[b] : nullptr; p.dw[b] = (dw_host && b < nb) ? dw_host[b] : nullptr;
+    p.bias[b] = nullptr; p.dbias[b] = nullptr;
+  }
   for (int j = 0; j < MT_MAXB * MT_MAXK; ++j) p.tap[j] = 0;
   for (int j = 0; j < nb * k; ++j) {
     UNET_REQUIRE(tap_host[j] >= 0 && tap_host[j] < n_taps, "merge_taps: tap index %d out of range", tap_host[j]);
@@ -1336,27 +1406,65 @@ int merge_setup(MergeK& p, const float* const* w_host, float* const* dw_host, in
 
 extern "C" int32_t unet_merge_taps_parts(int32_t co, int32_t ci) { return (int32_t)(((long long)co * ci + 255) / 256); }
 
-extern "C" int unet_merge_taps_fwd(const float* const* w_branch_host, const float* sw, int32_t n_branch, int32_t k,
-                                   int32_t co, int32_t ci, const int32_t* tap_index_host, int32_t n_taps, float* w_eff,
-                                   void* stream) {
+extern "C" int unet_merge_branches_fwd(const float* const* w_branch_host, const float* const* bias_branch_host,
+                                       const float* sw, int32_t softmax, int32_t n_branch, int32_t k, int32_t co, int32_t ci,
+                                       const int32_t* tap_index_host, int32_t n_taps, float* w_eff, float* b_eff,
+                                       float* sw_out, void* stream) {
   MergeK p;
   if (merge_setup(p, w_branch_host, nullptr, n_branch, k, co, ci, tap_index_host, n_taps)) return -1;
   UNET_REQUIRE(sw && w_eff, "merge_taps_fwd: null pointer");
+  UNET_REQUIRE((bias_branch_host == nullptr) == (b_eff == nullptr), "merge_taps_fwd: biases and b_eff come together");
+  p.softmax = softmax ? 1 : 0;
+  if (bias_branch_host)
+    for (int b = 0; b < n_branch; ++b) {
+      UNET_REQUIRE(bias_branch_host[b] != nullptr, "merge_taps_fwd: null branch bias");
+      p.bias[b] = bias_branch_host[b];
+    }
   hipLaunchKernelGGL(merge_taps_fwd_kernel, dim3((unsigned)((p.pairs + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), p, sw, w_eff);
+                     static_cast<hipStream_t>(stream), p, sw, w_eff, b_eff, sw_out);
   UNET_LAUNCH_CHECK("merge_taps_fwd");
+  return 0;
+}
+
+extern "C" int unet_merge_taps_fwd(const float* const* w_branch_host, const float* sw, int32_t n_branch, int32_t k,
+                                   int32_t co, int32_t ci, const int32_t* tap_index_host, int32_t n_taps, float* w_eff,
+                                   void* stream) {
+  return unet_merge_branches_fwd(w_branch_host, nullptr, sw, 0, n_branch, k, co, ci, tap_index_host, n_taps, w_eff, nullptr,
+                                 nullptr, stream);
+}
+
+extern "C" int unet_merge_branches_bwd(const float* const* w_branch_host, const float* const* bias_branch_host,
+                                       const float* sw, int32_t softmax, int32_t n_branch, int32_t k, int32_t co, int32_t ci,
+                                       const int32_t* tap_index_host, int32_t n_taps, const float* dw_eff,
+                                       const float* db_eff, float* const* dw_branch_host, float* const* dbias_branch_host,
+                                       float* dsw_part, float* dsw, void* stream) {
+  MergeK p;
+  if (merge_setup(p, w_branch_host, dw_branch_host, n_branch, k, co, ci, tap_index_host, n_taps)) return -1;
+  UNET_REQUIRE(sw && dw_eff && dw_branch_host && dsw_part, "merge_taps_bwd: null pointer");
+  for (int b = 0; b < n_branch; ++b) UNET_REQUIRE(p.dw[b] != nullptr, "merge_taps_bwd: null branch gradient");
+  const bool with_bias = db_eff != nullptr;
+  UNET_REQUIRE(!with_bias || (bias_branch_host && dbias_branch_host), "merge_taps_bwd: db_eff without the branch biases");
+  if (with_bias)
+    for (int b = 0; b < n_branch; ++b) {
+      UNET_REQUIRE(bias_branch_host[b] && dbias_branch_host[b], "merge_taps_bwd: null branch bias");
+      p.bias[b] = bias_branch_host[b];
+      p.dbias[b] = dbias_branch_host[b];
+    }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int parts = (int)((p.pairs + 255) / 256);
+  hipLaunchKernelGGL(merge_taps_bwd_kernel, dim3((unsigned)parts), dim3(256), 0, st, p, sw, dw_eff, dsw_part,
+                     with_bias ? db_eff : nullptr);
+  UNET_LAUNCH_CHECK("merge_taps_bwd");
+  if (dsw) {
+    hipLaunchKernelGGL(merge_taps_finish_kernel, dim3(1), dim3(256), 0, st, dsw_part, parts, n_branch, sw, dsw, softmax ? 1 : 0);
+    UNET_LAUNCH_CHECK("merge_taps_finish");
+  }
   return 0;
 }
 
 extern "C" int unet_merge_taps_bwd(const float* const* w_branch_host, const float* sw, int32_t n_branch, int32_t k,
                                    int32_t co, int32_t ci, const int32_t* tap_index_host, int32_t n_taps,
                                    const float* dw_eff, float* const* dw_branch_host, float* dsw_part, void* stream) {
-  MergeK p;
-  if (merge_setup(p, w_branch_host, dw_branch_host, n_branch, k, co, ci, tap_index_host, n_taps)) return -1;
-  UNET_REQUIRE(sw && dw_eff && dw_branch_host && dsw_part, "merge_taps_bwd: null pointer");
-  for (int b = 0; b < n_branch; ++b) UNET_REQUIRE(p.dw[b] != nullptr, "merge_taps_bwd: null branch gradient");
-  hipLaunchKernelGGL(merge_taps_bwd_kernel, dim3((unsigned)((p.pairs + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), p, sw, dw_eff, dsw_part);
-  UNET_LAUNCH_CHECK("merge_taps_bwd");
-  return 0;
+  return unet_merge_branches_bwd(w_branch_host, nullptr, sw, 0, n_branch, k, co, ci, tap_index_host, n_taps, dw_eff, nullptr,
+                                 dw_branch_host, nullptr, dsw_part, nullptr, stream);
 }

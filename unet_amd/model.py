@@ -506,15 +506,16 @@ class MultiScaleDilatedConv1d(nn.Module):
         self._tap_list = tuple(p[2] for p in pairs)
 
     def effective_weights(self) -> Tuple[Tensor, Tensor]:
-        w = F.softmax(self.scale_weights.float(), dim=0)
         ws = [b.conv.weight for b in self.branches]
-        if ws[0].is_cuda:
-            w_eff = ops.MergeTapsFn.apply(w, self._tap_list, self._geom.n_taps, *ws)
-        else:  # parameter-only algebra, used by CPU-side layout checks; the conv itself has no CPU path
-            st = (torch.stack(ws, dim=0).float() * w[:, None, None, None]).permute(0, 3, 1, 2)
-            st = st.reshape(-1, st.shape[2], st.shape[3])
-            w_eff = torch.zeros((self._geom.n_taps,) + tuple(st.shape[1:]), dtype=st.dtype).index_add(
-                0, torch.tensor(self._tap_list, dtype=torch.long), st)
+        if ws[0].is_cuda:      # softmax over the branches, merged taps and effective bias: one launch
+            return ops.MergeBranchesFn.apply(self.scale_weights, self._tap_list, self._geom.n_taps, len(ws), *ws,
+                                             *[b.conv.bias for b in self.branches])
+        # parameter-only algebra, used by CPU-side layout checks; the conv itself has no CPU path
+        w = F.softmax(self.scale_weights.float(), dim=0)
+        st = (torch.stack(ws, dim=0).float() * w[:, None, None, None]).permute(0, 3, 1, 2)
+        st = st.reshape(-1, st.shape[2], st.shape[3])
+        w_eff = torch.zeros((self._geom.n_taps,) + tuple(st.shape[1:]), dtype=st.dtype).index_add(
+            0, torch.tensor(self._tap_list, dtype=torch.long), st)
         b_eff = (torch.stack([b.conv.bias for b in self.branches], dim=0).float() * w[:, None]).sum(0)
         return w_eff, b_eff
 
@@ -570,8 +571,7 @@ class _UpMixin:
         geom, kidx = ops.geom_convt_k4s2p1()
 
         def w():                                                   # tap order (no index tensor: graph-capture safe)
-            wk = self.up.weight.permute(2, 1, 0)                   # [k, Cout, Cin] view
-            return torch.stack([wk[k] for k in kidx]), self.up.bias
+            return ops.TapOrderFn.apply(self.up.weight.permute(2, 1, 0), tuple(kidx)), self.up.bias   # [k, Cout, Cin] view
 
         up_params = (self.up.weight, self.up.bias)
         l_up = 2 * x.shape[1]

@@ -211,6 +211,80 @@ class MergeTapsFn(torch.autograd.Function):
         return (dsw[0].to(sw_dtype), None, None) + tuple(d.to(t) for d, t in zip(dws, w_dtypes))
 
 
+class TapOrderFn(torch.autograd.Function):
+    """w[order] along the tap axis for a PERMUTATION ``order`` (the transposed conv's taps in phase order): one copy each
+    way.  torch.stack of slices has the same forward, but its backward is a zero-fill, a copy and an add per slice
+    (11 launches per ConvTranspose1d and step)."""
+
+    @staticmethod
+    def forward(ctx, w, order: Tuple[int, ...]):
+        if sorted(order) != list(range(w.shape[0])):
+            raise ValueError(f"{order} is not a permutation of the {w.shape[0]} taps")
+        ctx.order = order
+        return torch.stack([w[k] for k in order])
+
+    @staticmethod
+    def backward(ctx, g):
+        inv = [0] * len(ctx.order)
+        for j, k in enumerate(ctx.order):
+            inv[k] = j
+        return torch.stack([g[j] for j in inv]), None
+
+
+class MergeBranchesFn(torch.autograd.Function):
+    """(w_eff, b_eff) of MultiScaleDilatedConv1d (models.py:752-759) from the RAW scale_weights, the branch weights
+    and the branch biases: softmax over the branches, merged taps and the effective bias in one launch
+    (unet_merge_branches_fwd); backward in two (branch gradients + partials, then the sum of the partials taken
+    through the softmax).  As separate torch ops around MergeTapsFn this was 5 launches forward and 8 backward per
+    conv."""
+
+    @staticmethod
+    def forward(ctx, scale_weights, tap_index: Tuple[int, ...], n_taps: int, nb: int, *wb):
+        lib = _lib.load()
+        branch_w, branch_b = wb[:nb], wb[nb:]
+        co, ci, k = branch_w[0].shape
+        ws = [_f32c(w.detach()) for w in branch_w]
+        bs = [_f32c(b.detach()) for b in branch_b]
+        raw = _f32c(scale_weights.detach())
+        dev = raw.device
+        w_eff = torch.empty((n_taps, co, ci), dtype=torch.float32, device=dev)
+        b_eff = torch.empty(co, dtype=torch.float32, device=dev)
+        sw = torch.empty(nb, dtype=torch.float32, device=dev)
+        wp = (C.c_void_p * nb)(*[w.data_ptr() for w in ws])
+        bp = (C.c_void_p * nb)(*[b.data_ptr() for b in bs])
+        taps = (C.c_int32 * (nb * k))(*tap_index)
+        check(lib.unet_merge_branches_fwd(wp, bp, _p(raw), 1, nb, k, co, ci, taps, n_taps, _p(w_eff), _p(b_eff), _p(sw),
+                                          _stream()), "unet_merge_branches_fwd")
+        ctx.save_for_backward(sw, *ws, *bs)
+        ctx.meta = (tuple(tap_index), n_taps, nb, scale_weights.dtype, [t.dtype for t in wb])
+        return w_eff, b_eff
+
+    @staticmethod
+    def backward(ctx, dw_eff, db_eff):
+        lib = _lib.load()
+        tap_index, n_taps, nb, sw_dtype, dtypes = ctx.meta
+        sw, *rest = ctx.saved_tensors
+        ws, bs = rest[:nb], rest[nb:]
+        co, ci, k = ws[0].shape
+        dev = sw.device
+        dw_eff = _f32c(dw_eff) if dw_eff is not None else torch.zeros((n_taps, co, ci), dtype=torch.float32, device=dev)
+        db_eff = _f32c(db_eff) if db_eff is not None else torch.zeros(co, dtype=torch.float32, device=dev)
+        dws = [torch.empty_like(w) for w in ws]
+        dbs = [torch.empty_like(b) for b in bs]
+        parts_n = int(lib.unet_merge_taps_parts(co, ci))
+        dsw_part = torch.empty((parts_n, nb), dtype=torch.float32, device=dev)
+        draw = torch.empty(nb, dtype=torch.float32, device=dev)
+        wp = (C.c_void_p * nb)(*[w.data_ptr() for w in ws])
+        bp = (C.c_void_p * nb)(*[b.data_ptr() for b in bs])
+        dwp = (C.c_void_p * nb)(*[w.data_ptr() for w in dws])
+        dbp = (C.c_void_p * nb)(*[b.data_ptr() for b in dbs])
+        taps = (C.c_int32 * (nb * k))(*tap_index)
+        check(lib.unet_merge_branches_bwd(wp, bp, _p(sw), 1, nb, k, co, ci, taps, n_taps, _p(dw_eff), _p(db_eff), dwp, dbp,
+                                          _p(dsw_part), _p(draw), _stream()), "unet_merge_branches_bwd")
+        grads = [d.to(t) for d, t in zip(dws + dbs, dtypes)]
+        return (draw.to(sw_dtype), None, None, None) + tuple(grads)
+
+
 # ---------------------------------------------------------------------------------------------
 # conv launchers
 # ---------------------------------------------------------------------------------------------
