@@ -101,7 +101,8 @@ enum { UNET_VARIANT_NONE = 0,
        UNET_VARIANT_FWD_TILED = 2,     /* conv_fwd2_kernel_192/_128/_64: bf16, buffer LDS-DMA, halo tile + tap loop */
        UNET_VARIANT_FWD_STREAM = 3,    /* conv_stream_kernel: bf16 single-tap convs, persistent, 256x128 tiles */
        UNET_VARIANT_WGRAD_GENERIC = 11,/* conv_wgrad_kernel */
-       UNET_VARIANT_WGRAD_PAIRED = 12  /* conv_wgrad2_kernel: bf16, two taps per block, LDS-DMA ring */ };
+       UNET_VARIANT_WGRAD_PAIRED = 12, /* conv_wgrad2_kernel: bf16, two taps per block, LDS-DMA ring */
+       UNET_VARIANT_WGRAD_WIDE = 13    /* conv_wgrad3_kernel: bf16 single-tap convs, >= 512 channels, 256x256 tiles */ };
 int unet_conv1d_last_variant(void);
 
 /* Weight gradient:  dw[j][co][ci] (fp32, contiguous, ci over c1+c2) =

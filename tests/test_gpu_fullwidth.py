@@ -147,13 +147,15 @@ def test_fullwidth_bf16_close_to_reference(name):
 # ---------------------------------------------------------------------------------------------------------------
 # conv kernels at config-B layer shapes, dispatcher's choice asserted
 # ---------------------------------------------------------------------------------------------------------------
-FWD_TILED, FWD_STREAM, WGRAD_PAIRED = 2, 3, 12
+FWD_TILED, FWD_STREAM, WGRAD_PAIRED, WGRAD_WIDE = 2, 3, 12, 13
 LAYER_CASES = [
     # (tag, cin, cout, L, k, stride, dilation, expected forward variant)
     ("mid_k3_c1024", 1024, 1024, 1024, 3, 1, 1, FWD_TILED),
     ("enc_k3_s2_c512", 512, 1024, 2048, 3, 2, 1, FWD_TILED),
     ("film_k1_c1024", 1024, 1024, 1024, 1, 1, 1, FWD_STREAM),
     ("film_k1_c256", 256, 256, 4096, 1, 1, 1, FWD_STREAM),
+    ("film_k1_c512", 512, 512, 2048, 1, 1, 1, FWD_STREAM),
+    ("k1_c512_ragged", 512, 768, 1000, 1, 1, 1, FWD_STREAM),
     ("branch_k7_d32_c512", 512, 512, 2048, 7, 1, 32, FWD_TILED),
     ("outc_k3", 256, 32, 4096, 3, 1, 1, FWD_TILED),
     ("inc_k7_d16_cin32", 32, 256, 4096, 7, 1, 16, FWD_TILED),
@@ -183,7 +185,8 @@ def test_conv_kernels_at_config_b_layer_shapes(case):
     dyd = dy.permute(0, 2, 1).contiguous()
     y.backward(dyd)
     ops.conv_wgrad_raw(geom, xd.detach(), None, dyd, cout)          # same call on this thread: which kernel ran
-    assert int(lib.unet_conv1d_last_variant()) == WGRAD_PAIRED
+    wide = k == 1 and cin % 256 == 0 and cout % 256 == 0 and (cin // 256) * (cout // 256) >= 4
+    assert int(lib.unet_conv1d_last_variant()) == (WGRAD_WIDE if wide else WGRAD_PAIRED)
     assert rel(y.permute(0, 2, 1), yr) < 1e-2
     assert rel(xd.grad.permute(0, 2, 1), xr.grad) < 1e-2
     assert rel(wd.grad, wr.grad) < 1e-2

@@ -1229,6 +1229,164 @@ __global__ __launch_bounds__(THREADS, 2) void conv_wgrad2_kernel(const Wg2K p) {
   if (two) store(acc1, p.g_tapb[grp]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of SINGLE-TAP convs with wide channel counts (the FiLM q_proj / out_proj at C >= 512,
+// models.py:492,495): 256(co) x 256(ci) output tile per workgroup.  With the 128 x 128 tiles of conv_wgrad2 every
+// dy slab is staged once per input-channel tile and every x slab once per output-channel tile -- at C = 512 that is
+// 1 GiB moved from L2 to LDS for 256 MiB of operands, and the kernel is bound by exactly that fill.  Eight waves
+// (4 output-channel groups of 64 x 2 input-channel halves of 128; 128 accumulator registers per lane), one workgroup
+// per CU, stages of 64 positions = four 16 KiB sub-tiles [dy co 0-127 | dy co 128-255 | x ci 0-127 | x ci 128-255] in the
+// layout of conv_wgrad2 (so the transposed ds_read_b64_tr_b16 fragment reads and their swizzle carry over), two stages.
+// (A ring of four 32-position stages with counted vmcnt waits, three stages in flight, measured 15 % SLOWER: twice the
+// barriers per MFMA.)  film512 121 -> 109 us, film1024 222 -> 197 us incl. the slab sum (scripts/ab_conv.sh).
+// ---------------------------------------------------------------------------------------------
+constexpr int WG3_THREADS = 512;
+constexpr int WG3_BKP = 64;
+constexpr int WG3_SUB = WG3_BKP * 256;          // one sub-tile: 64 rows x 256 B
+constexpr int WG3_STAGE = 4 * WG3_SUB;          // 64 KiB
+
+struct Wg3K {
+  const char* x; const char* dy; float* slab;
+  long long x_ns, dy_ns;
+  int x_ld, dy_ld;
+  int c_in, c_out, l_in, mcount, n;
+  int off0;            // input row of output position 0
+  int mt2, kt2, splits;
+};
+
+__global__ __launch_bounds__(WG3_THREADS, 1) void conv_wgrad3_kernel(const Wg3K p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  int wg = xcd_remap(blockIdx.x, gridDim.x);
+  // tiles fastest, split slowest: the (few) tiles of one split are neighbours on one XCD, so that split's dy and x rows
+  // are fetched into that L2 once and serve every tile
+  const int kt = wg % p.kt2; wg /= p.kt2;
+  const int mt = wg % p.mt2;
+  const int split = wg / p.mt2;
+  const int co0 = mt * 256, ci0 = kt * 256;
+  const int mchunks = (p.mcount + WG3_BKP - 1) / WG3_BKP;
+  const int items = p.n * mchunks;
+  const int per = (items + p.splits - 1) / p.splits;
+  const int it0 = split * per;
+  const int it1 = min(items, it0 + per);
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging: a wave fills half of ONE sub-tile (8 pieces of 4 rows); rows / channels outside the window fail the
+  // descriptor's range check and arrive as zeros ----------------------------------------------------------------
+  constexpr unsigned OOB = 0x80000000u;
+  const int sub = wave >> 1;                         // 0, 1: dy halves; 2, 3: x halves
+  const bool is_x = sub >= 2;
+  const int ld = is_x ? p.x_ld : p.dy_ld;
+  const int cbase = is_x ? ci0 + (sub - 2) * 128 : co0 + sub * 128;
+  const int climit = is_x ? p.c_in : p.c_out;
+  const int rl = lane >> 4, pc = lane & 15;
+  unsigned voff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = ((wave & 1) * 8 + i) * 4 + rl;
+    const int e0 = cbase + (swz_t(row, pc) << 3);
+    voff[i] = e0 < climit ? (unsigned)((row * ld + e0) * 2) : OOB;
+  }
+  const unsigned win_bytes = is_x ? (unsigned)(((p.l_in - 1) * p.x_ld + p.c_in) * 2)
+                                  : (unsigned)(((p.mcount - 1) * p.dy_ld + p.c_out) * 2);
+  const char* src = is_x ? p.x : p.dy;
+  const long long ns = is_x ? p.x_ns : p.dy_ns;
+  const int roff = is_x ? p.off0 : 0;
+  int cur_n = it0 / mchunks, cur_mc = it0 - cur_n * mchunks;
+
+  auto issue = [&](int buf) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long long)cur_n * ns * 2), 0, win_bytes, 0x00020000);
+    const unsigned io = (unsigned)((cur_mc * WG3_BKP + roff) * ld * 2);     // may be "negative": wraps past the range
+    char* dst = smem + buf * WG3_STAGE + sub * WG3_SUB + (wave & 1) * 8 * 1024;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
+                                               voff[i] + io, 0, 0, 0);
+    if (++cur_mc == mchunks) { cur_mc = 0; ++cur_n; }
+  };
+
+  // ---- per-lane LDS read addresses (stage 0) -------------------------------------------------------------------
+  const int q = l15 >> 2, pp = l15 & 3;
+  int a_addr[2][4], b_addr[2][8];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int row = lq * 8 + half * 4 + q;
+    const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      a_addr[half][i] = (wm >> 1) * WG3_SUB + row * 256 + (((((wm & 1) * 64 + i * 16) >> 3) + (pp >> 1)) ^ sw) * 16 + 8 * (pp & 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      b_addr[half][i] = (2 + wn) * WG3_SUB + row * 256 + ((((i * 16) >> 3) + (pp >> 1)) ^ sw) * 16 + 8 * (pp & 1);
+  }
+  auto tr_read = [&](int addr) -> bf16x4 {
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + addr));
+    return __builtin_bit_cast(bf16x4, v);
+  };
+
+  auto compute = [&](int stage_off) {
+#pragma unroll
+    for (int ks = 0; ks < WG3_BKP / 32; ++ks) {
+      const int o = stage_off + ks * 32 * 256;
+      bf16x8 a[4], b[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          bf16x4 vb = tr_read(a_addr[half][mi] + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[mi][half * 4 + e] = vb[e];
+        }
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+          bf16x4 vb = tr_read(b_addr[half][ni] + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[ni][half * 4 + e] = vb[e];
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
+  };
+
+  if (it0 < it1) {
+    issue(0);
+    int nbuf = 1;
+    for (int it = it0; it < it1; ++it) {
+      __syncthreads();   // this stage has landed (vmcnt(0) + barrier); every wave is done reading the other one
+      if (it + 1 < it1) issue(nbuf);
+      compute((nbuf ^ 1) * WG3_STAGE);
+      nbuf ^= 1;
+    }
+  }
+
+  float* slab = p.slab + (long long)split * p.c_out * p.c_in;
+#pragma unroll
+  for (int ni = 0; ni < 8; ++ni) {
+    const int ci = ci0 + wn * 128 + ni * 16 + l15;
+    if (ci >= p.c_in) continue;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wm * 64 + mi * 16 + lq * 4 + r;
+        if (co < p.c_out) slab[(long long)co * p.c_in + ci] = acc[mi][ni][r];
+      }
+  }
+}
+
 // out = sum of the split-K slabs, in slab order (deterministic).  16 bytes per lane and eight slabs' loads in flight
 // per thread: as one scalar load per slab in a run-time loop the sum of a 1x1 conv's 32 slabs was 32 dependent
 // memory round trips (16 us for 256 KiB of output).
@@ -1627,6 +1785,23 @@ bool wgrad2_ok(const UnetConvDesc* d, const void* x1, const void* x2, const void
   return true;
 }
 
+// the 256 x 256-tile kernel: one tap at unit stride, one source, whole 256-channel tiles, at least four of them
+bool wgrad3_ok(const UnetConvDesc* d) {
+  const char* env = getenv("UNET_WGRAD3");
+  if (env && atoi(env) == 0) return false;
+  return d->dtype == UNET_BF16 && d->n_taps == 1 && d->stride == 1 && d->up == 1 && d->c2 == 0 && d->c1 % 256 == 0 &&
+         d->c_out % 256 == 0 && (long long)(d->c1 / 256) * (d->c_out / 256) >= 4;
+}
+int wgrad3_splits(const UnetConvDesc* d) {
+  // one workgroup per CU: enough splits to give every CU one, never more items than there are
+  const long long tiles = (long long)(d->c1 / 256) * (d->c_out / 256);
+  const long long items = (long long)d->n * cdiv(d->l_out, WG3_BKP);
+  long long s = (256 + tiles - 1) / tiles;
+  if (s > 64) s = 64;
+  if (s > items) s = items;
+  return (int)(s < 1 ? 1 : s);
+}
+
 int wgrad2_splits(const UnetConvDesc* d, const Phases& ph, int groups) {
   // Split-K factor from a small cost model: rounds of 512 resident blocks (2 per CU) x steps per block, plus the
   // HBM round trip of the fp32 slabs (written once, read once by the reducer).  Few, long blocks keep the slab
@@ -1659,6 +1834,7 @@ extern "C" size_t unet_conv1d_wgrad_workspace_bytes(const UnetConvDesc* d) {
     wgrad_groups(d, &g);
     const int s2 = wgrad2_splits(d, ph, g.n);
     if (s2 > s) s = s2;
+    if (wgrad3_ok(d) && wgrad3_splits(d) > s) s = wgrad3_splits(d);
   }
   return (size_t)s * d->n_taps * d->c_out * (d->c1 + d->c2) * sizeof(float);
 }
@@ -1731,6 +1907,33 @@ int wgrad_impl(const UnetConvDesc* d, const void* x1, const void* x2, const void
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long count = (long long)d->n_taps * d->c_out * (d->c1 + d->c2);
   g_last_variant = UNET_VARIANT_WGRAD_GENERIC;
+  if (wgrad2_ok(d, x1, x2, dy) && wgrad3_ok(d)) {
+    g_last_variant = UNET_VARIANT_WGRAD_WIDE;
+    const int splits = wgrad3_splits(d);
+    const size_t need = (size_t)splits * count * sizeof(float);
+    UNET_REQUIRE(workspace && ws_bytes >= need, "conv_wgrad: workspace %zu bytes < %zu needed", ws_bytes, need);
+    Wg3K k;
+    k.x = static_cast<const char*>(x1); k.dy = static_cast<const char*>(dy); k.slab = static_cast<float*>(workspace);
+    k.x_ns = d->x1_ns; k.dy_ns = d->y_ns; k.x_ld = d->x1_ld; k.dy_ld = d->y_ld;
+    k.c_in = d->c1; k.c_out = d->c_out; k.l_in = d->l_in; k.mcount = ph.mcount[0]; k.n = d->n;
+    k.off0 = d->tap_off[0];
+    k.mt2 = d->c_out / 256; k.kt2 = d->c1 / 256; k.splits = splits;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG3_STAGE);
+      UNET_REQUIRE(e == hipSuccess, "conv_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      attr_set = true;
+    }
+    const long long blocks = (long long)k.mt2 * k.kt2 * splits;
+    hipLaunchKernelGGL(conv_wgrad3_kernel, dim3((unsigned)blocks), dim3(WG3_THREADS), 2 * WG3_STAGE, st, k);
+    UNET_LAUNCH_CHECK("conv_wgrad3");
+    const long long cols = (count & 3) ? count : count >> 2;
+    int rb = (int)((cols + 255) / 256 > 4096 ? 4096 : (cols + 255) / 256);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(rb), dim3(256), 0, st, k.slab, dw, count, splits);
+    UNET_LAUNCH_CHECK("slab_reduce");
+    return 0;
+  }
   if (wgrad2_ok(d, x1, x2, dy)) {
     g_last_variant = UNET_VARIANT_WGRAD_PAIRED;
     WgGroups g;

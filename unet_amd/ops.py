@@ -66,7 +66,7 @@ PROFILE: Optional[list] = None
 
 # include/unet_hip.h UNET_VARIANT_*: the kernel the dispatcher picked for the launch just made
 _VARIANTS = {1: "conv_fwd_kernel", 2: "conv_fwd2_kernel", 3: "conv_stream_kernel", 11: "conv_wgrad_kernel",
-             12: "conv_wgrad2_kernel"}
+             12: "conv_wgrad2_kernel", 13: "conv_wgrad3_kernel"}
 
 
 class _Timed:
