@@ -238,8 +238,10 @@ def test_inference_reuses_packed_weights_until_a_parameter_changes():
         y2 = model(ob, **_kw(g))
         assert len(ops._PACK_CACHE) == n_entries
     assert rel(y2, y0) > 1e-3
-    # and the cached path computes what the training-mode path (no cache) computes from the same weights
+    # and the cached path computes what the path with autograd on (no cache) computes from the same weights -- up to bf16
+    # rounding: under no_grad the norm + GELU + SE scale is one fused pass (the product is rounded once), with autograd
+    # the activation is stored in bf16 before the scale (rounded twice)
     with torch.enable_grad():
         y3 = model(ob, **_kw(g))
-    assert torch.equal(y3.detach(), y2)
+    assert rel(y3.detach(), y2) < 5e-3
     ops.clear_pack_cache()

@@ -60,6 +60,11 @@ def _as_ncl(x: Tensor) -> Tensor:
 # ---------------------------------------------------------------------------------------------
 # normalisation (models.py:537-555, 801-817) + activation (+ SE squeeze) on the HIP kernels
 # ---------------------------------------------------------------------------------------------
+def _data_parallel() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def _uses_batch_stats(norm: nn.Module) -> bool:
     """BatchNorm that normalises with the statistics of its own input: the conv in front of it can deliver them."""
     return isinstance(norm, nn.BatchNorm1d) and (norm.training or norm.running_mean is None) and torch.is_grad_enabled()
@@ -91,6 +96,16 @@ def _norm_act_se(y: Tensor, norm: nn.Module, act_id: int, se: "SqueezeExcitation
     fused autograd node; every other norm takes the general kernels followed by the SE scale."""
     if FUSE_SE and isinstance(norm, nn.BatchNorm1d) and (norm.training or norm.running_mean is None):
         return _norm_act(y, norm, act_id, False, se=se)
+    if FUSE_SE and isinstance(norm, nn.BatchNorm1d) and not torch.is_grad_enabled() and y.is_cuda:
+        # eval-mode BatchNorm under no_grad (sliding-window inference, evaluate()): running statistics as the affine
+        n, _, c = y.shape
+        rstd = torch.rsqrt(norm.running_var.double() + norm.eps)
+        g = norm.weight.detach().double() if norm.weight is not None else torch.ones_like(rstd)
+        bt = norm.bias.detach().double() if norm.bias is not None else torch.zeros_like(rstd)
+        a = (rstd * g).float()
+        b = (bt - norm.running_mean.double() * rstd * g).float()
+        return ops.norm_act_se_inference(y, a[None, :].expand(n, c).contiguous(), b[None, :].expand(n, c).contiguous(),
+                                         act_id, se.fc[0].weight, se.fc[2].weight)
     z, pool = _norm_act(y, norm, act_id, True)
     return ops.ScaleFn.apply(z, se.gate_from_pool(pool, z.shape[1]))
 
@@ -1019,8 +1034,11 @@ class CondUNet1D(nn.Module):
         # The FiLM projections depend on the embedding alone: all blocks' k / v / gate maps run as ONE launch here
         # (and one backward launch after the last block's backward) instead of one per block on the critical path.
         # Not under gradient checkpointing, whose recomputation must replay each block's own launches.
+        # Not in a data-parallel job either: the hoisted node's backward runs after the LAST block's, so every block's
+        # k / v / gate gradients would arrive at the very end and hold back the gradient bucket they live in
+        # (dp.BucketedGradAllReduce launches a bucket's all-reduce when its last gradient lands).
         films = []
-        if HOIST_FILM and emb is not None and not (self.gradient_checkpointing and self.training):
+        if HOIST_FILM and emb is not None and not (self.gradient_checkpointing and self.training) and not _data_parallel():
             blocks = [self.inc, *self.encoders, *[getattr(d, "block", None) for d in self.decoders]]
             films = [b.film for b in blocks if isinstance(getattr(b, "film", None), FiLM) and b.film.cond_mode != "none"]
             if len(films) > 1:

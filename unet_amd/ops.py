@@ -855,6 +855,26 @@ class BatchNormActSEFn(torch.autograd.Function):
         return dy, dgamma, dbeta, None, None, None, None, None, dw0.to(ctx.wdtypes[0]), dw2.to(ctx.wdtypes[1])
 
 
+def norm_act_se_inference(y: Tensor, a: Tensor, b: Tensor, act_id: int, w0: Tensor, w2: Tensor) -> Tensor:
+    """act(a*y+b) * SE-gate for inference (no autograd): pool-only pass, the SE MLP, one fused apply pass -- 3 activation
+    touches instead of the 4 of norm+act(+pool) followed by the SE scale.  a, b: [N, C] fp32."""
+    lib = _lib.load()
+    _need_cuda(y)
+    y = y.contiguous()
+    n, rows, c = y.shape
+    dt, st = _dt(y), _stream()
+    (pbuf,) = _part_buf(y)
+    check(lib.unet_affine_pool(dt, _p(y), _p(a), _p(b), act_id, _p(pbuf), n, rows, c, st), "unet_affine_pool")
+    pool = sum_parts(pbuf)
+    gelu, sig = _lib.SMALL_ACT["gelu"], _lib.SMALL_ACT["sigmoid"]
+    (h,), _ = _small_fwd(pool, (gelu,), (1.0 / rows,), [_f32c(w0)], [None])
+    (sd,), _ = _small_fwd(h, (sig,), (1.0,), [_f32c(w2)], [None])
+    z = torch.empty_like(y)
+    check(lib.unet_affine_act_scale_fwd(dt, _p(y), _p(a), _p(b), act_id, _p(sd), _p(z), n, rows, c, st),
+          "unet_affine_act_scale_fwd")
+    return z
+
+
 def activation(x: Tensor, act_id: int) -> Tensor:
     return AffineActFn.apply(x, None, None, None, act_id, False)
 
