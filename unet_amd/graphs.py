@@ -31,6 +31,14 @@ import torch.distributed as dist
 from .dp import BucketedGradAllReduce, _has_avg, group_size
 
 
+def _capture_mode() -> str:
+    """With a process group up, its watchdog thread polls the events of earlier collectives (the warm-up steps', the
+    start-up broadcast's) while this thread captures: under the default "global" mode such a call from ANOTHER thread
+    invalidates the capture (seen as an intermittent abort inside the captured backward).  "thread_local" confines the
+    capture's restrictions to the capturing thread, which is the only one that issues work here."""
+    return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+
+
 class GraphedTrainStep:
     """Capture ``loss = loss_fn(model(*inputs), *targets); loss.backward(); clip; optimizer.step()``.
 
@@ -90,18 +98,18 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         if self.world == 1:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
                 self.loss = fwd_bwd()
                 update()
             self.graph_update = None
         else:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
                 self.loss = fwd_bwd()
             self.static_grads = [p.grad for p in self.params]
             for p, v in zip(self.params, self._views):
                 p.grad = v                                   # the optimizer reads the reduced buckets
             self.graph_update = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_update):
+            with torch.cuda.graph(self.graph_update, capture_error_mode=_capture_mode()):
                 update()
 
     # -- data parallel, collectives inside the graph ----------------------------------------------
@@ -133,7 +141,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             self.loss = full_step()
         self.graph_update = None
 
