@@ -84,6 +84,9 @@ def parse():
     ap.add_argument("--graph-overlap", action="store_true", help="N > 1: ONE captured graph with the bucket all-reduces "
                     "inside it, forked off the backward stream (graphs.GraphedTrainStep(overlap=True)); falls back to the "
                     "eager hook-driven path if the capture is refused")
+    ap.add_argument("--dp-selftest", action="store_true", help="N = 1 only: run the N > 1 code path (eager launches, bucket "
+                    "hooks, one RCCL all-reduce per bucket) through a one-rank process group with the collectives forced on; "
+                    "measures what the data-parallel machinery costs beside the step, not the xGMI transport")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one (hook-driven overlapped "
                     "all-reduce) instead of replaying the captured HIP graph")
     return ap.parse_args()
@@ -149,6 +152,11 @@ def main():
     if world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif args.dp_selftest:
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29733", world_size=1, rank=0,
+                                device_id=torch.device("cuda", 0))
+        args.eager = True
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -212,7 +220,7 @@ def main():
             opt = torch.optim.AdamW(groups, lr=2e-4, betas=(0.7595905764360957, 0.920298282605139),
                                     weight_decay=0.0, fused=True)
     if graphed is None:
-        reducer = BucketedGradAllReduce(model.parameters())
+        reducer = BucketedGradAllReduce(model.parameters(), force=args.dp_selftest)
 
     def step():
         if graphed is not None:
@@ -282,7 +290,7 @@ def main():
         "data": "synthetic N(0,1) windows, random-init weights (reference init, seed 0)",
         "config": {"workload": wl_descr + f", {c_in}ch x {T} windows, {B} windows/GPU, fwd + L1[500:4500] + bwd + "
                                "grad all-reduce + clip 5.0 + AdamW", "windows_per_gpu": B, "params": n_params,
-                   "parallelism": f"dp{world}", "launch": mode, "conditioning": args.conditioning,
+                   "parallelism": f"dp{world}" + (" (one-rank RCCL group, collectives forced)" if args.dp_selftest else ""), "launch": mode, "conditioning": args.conditioning,
                    "attention": args.attention},
         "final_loss": float(loss.item()), "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
         "ms_each_step": [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(args.steps)],
@@ -326,7 +334,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.cpu_windows if args.workload != "C" else max(1, args.cpu_windows // 4), cfg, gflop_fwd)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.dp_selftest:
         dist.destroy_process_group()
 
 
