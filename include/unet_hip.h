@@ -79,6 +79,20 @@ int unet_conv1d_pack(int32_t dtype, const float* w, int64_t tap_stride, int64_t 
                      int32_t row_lo, int32_t rows, int32_t col_lo, int32_t c1, int32_t c2,
                      void* packed, void* stream);
 
+/* Up to UNET_PACK_MAX_JOBS images in one launch, each described as a unet_conv1d_pack call: a training step packs a
+ * conv's forward image together with the transposed image(s) its data gradient will read (the weights are the same
+ * until the optimizer runs), which halves the pack launches of a step.  has_tap_src = 0: taps in order. */
+#define UNET_PACK_MAX_JOBS 3
+typedef struct UnetPackJob {
+  const float* w;
+  int64_t tap_stride, row_stride, col_stride;
+  int32_t n_taps, has_tap_src;
+  int32_t tap_src[UNET_MAX_TAPS];
+  int32_t row_lo, rows, col_lo, c1, c2;
+  void* packed;
+} UnetPackJob;
+int unet_conv1d_pack_multi(int32_t dtype, const UnetPackJob* jobs, int32_t n_jobs, void* stream);
+
 int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void* x2, const void* w_packed,
                     const float* bias, const void* res, void* y, void* stream);
 

@@ -342,3 +342,44 @@ def test_conv_epilogue_statistics(shape):
         outs.append((z, rm, rv))
     assert rel(outs[0][0], outs[1][0]) < 1e-5
     assert rel(outs[0][1], outs[1][1]) < 1e-5 and rel(outs[0][2], outs[1][2]) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_pack_multi_images_equal_single_packs(dtype, stride):
+    """unet_conv1d_pack_multi: the forward image and both data-gradient images of a two-source conv, written by one
+    launch, are bit-identical to the three unet_conv1d_pack launches they replace; and ConvFn's backward on the images
+    packed in forward gives the gradients of the path that packs in backward."""
+    from unet_amd import ops
+    torch.manual_seed(5)
+    dev = "cuda"
+    c1, c2, co, k = 72, 40, 136, 7            # ragged: not multiples of the 128-row tile or the K chunk
+    geom = ops.geom_conv(k, stride=stride)
+    w = torch.randn(k, co, c1 + c2, device=dev)[:, :, :].contiguous()
+    dt = ops._dt(torch.empty(0, dtype=dtype))
+    jobs = [dict(transpose=False, tap_src=None, n_taps=k, row_lo=0, rows=co, c1=c1, c2=c2),
+            ops._dgrad_pack_job(geom, w, 0, c1), ops._dgrad_pack_job(geom, w, c1, c2)]
+    many = ops.pack_weights_multi(w, dt, jobs)
+    for img, j in zip(many, jobs):
+        assert torch.equal(img, ops.pack_weights(w, dt, **j))
+    assert torch.equal(ops.pack_weights_multi(w, dt, jobs[:2])[1], many[1])
+    with pytest.raises(ValueError):
+        ops.pack_weights_multi(w, dt, jobs + jobs[:1])
+
+    n, l = 3, 200
+    l_out = (l + stride - 1) // stride if stride == 2 else l
+    x1 = torch.randn(n, l, c1, device=dev, dtype=dtype, requires_grad=True)
+    x2 = torch.randn(n, l, c2, device=dev, dtype=dtype, requires_grad=True)
+    wp = w.clone().requires_grad_(True)
+    l_out = ops.conv(x1, wp, None, geom, l // stride, x2=x2).shape[1]
+    g = torch.randn(n, l_out, co, device=dev, dtype=dtype)
+    res = {}
+    for flag in (True, False):
+        ops.DUAL_PACK = flag
+        try:
+            y = ops.conv(x1, wp, None, geom, l_out, x2=x2)
+            res[flag] = (y,) + torch.autograd.grad(y, (x1, x2, wp), g)
+        finally:
+            ops.DUAL_PACK = True
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)

@@ -17,6 +17,19 @@ BF16, F32 = 0, 1
 ACT_IDS = {"none": 0, "relu": 1, "leaky_relu": 2, "gelu": 3, "silu": 4, "mish": 5}
 
 
+class PackJob(C.Structure):
+    """Mirror of UnetPackJob (include/unet_hip.h)."""
+    _fields_ = [
+        ("w", C.c_void_p), ("tap_stride", C.c_int64), ("row_stride", C.c_int64), ("col_stride", C.c_int64),
+        ("n_taps", C.c_int32), ("has_tap_src", C.c_int32), ("tap_src", C.c_int32 * MAX_TAPS),
+        ("row_lo", C.c_int32), ("rows", C.c_int32), ("col_lo", C.c_int32), ("c1", C.c_int32), ("c2", C.c_int32),
+        ("packed", C.c_void_p),
+    ]
+
+
+PACK_MAX_JOBS = 3
+
+
 class ConvDesc(C.Structure):
     """Mirror of UnetConvDesc (include/unet_hip.h)."""
     _fields_ = [
@@ -53,6 +66,7 @@ _SIGNATURES = {
     "unet_conv1d_packed_bytes": (C.c_size_t, [_i32, _i32, _i32, _i32, _i32]),
     "unet_conv1d_pack": (C.c_int, [_i32, _vp, _i64, _i64, _i64, _i32, C.POINTER(_i32), _i32, _i32, _i32,
                                    _i32, _i32, _vp, _vp]),
+    "unet_conv1d_pack_multi": (C.c_int, [_i32, C.POINTER(PackJob), _i32, _vp]),
     "unet_conv1d_fwd": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "unet_conv1d_stats_max_parts": (_i32, [C.POINTER(ConvDesc)]),
     "unet_conv1d_fwd_stats": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp]),

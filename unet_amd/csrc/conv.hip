@@ -778,7 +778,7 @@ struct PackK {
 };
 
 template <bool F32>
-__global__ __launch_bounds__(256) void conv_pack_kernel(const PackK p) {
+__device__ __forceinline__ void pack_job(const PackK& p) {
   typedef typename Elem<F32>::T T;
   constexpr int EPC = Elem<F32>::EPC;
   constexpr int KC = EPC * 8;
@@ -811,6 +811,20 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const PackK p) {
     }
     *reinterpret_cast<u32x4*>(p.out + idx * 16) = v.u;
   }
+}
+
+template <bool F32>
+__global__ __launch_bounds__(256) void conv_pack_kernel(const PackK p) { pack_job<F32>(p); }
+
+// up to three images in one launch (a conv's forward image and the transposed images its data gradients will need):
+// every block walks the jobs in turn, so nothing in a job's loop depends on which job it is
+struct PackM { PackK k[3]; int n; };
+
+template <bool F32>
+__global__ __launch_bounds__(256) void conv_pack_multi_kernel(const PackM p) {
+  pack_job<F32>(p.k[0]);
+  if (p.n > 1) pack_job<F32>(p.k[1]);
+  if (p.n > 2) pack_job<F32>(p.k[2]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1576,26 +1590,58 @@ extern "C" size_t unet_conv1d_packed_bytes(int32_t dtype, int32_t n_taps, int32_
   return (size_t)n_taps * cdiv(rows, BM) * kct * WTILE_BYTES;
 }
 
+namespace {
+int fill_pack(PackK* k, int32_t dtype, const float* w, int64_t tap_stride, int64_t row_stride, int64_t col_stride,
+              int32_t n_taps, const int32_t* tap_src_host, int32_t row_lo, int32_t rows, int32_t col_lo, int32_t c1,
+              int32_t c2, void* packed) {
+  UNET_REQUIRE(n_taps > 0 && n_taps <= UNET_MAX_TAPS && rows > 0 && c1 > 0 && c2 >= 0, "pack: bad sizes");
+  UNET_REQUIRE(w && packed && aligned16(packed), "pack: null or misaligned pointer");
+  k->w = w; k->ts = tap_stride; k->rs = row_stride; k->cs = col_stride;
+  k->n_taps = n_taps; k->row_lo = row_lo; k->rows = rows; k->col_lo = col_lo; k->c1 = c1; k->c2 = c2;
+  k->kc1 = kchunks(dtype, c1); k->kctot = k->kc1 + (c2 > 0 ? kchunks(dtype, c2) : 0);
+  k->mtiles = cdiv(rows, BM);
+  for (int j = 0; j < UNET_MAX_TAPS; ++j) k->tap_src[j] = j < n_taps ? (tap_src_host ? tap_src_host[j] : j) : 0;
+  k->out = static_cast<char*>(packed);
+  return 0;
+}
+long long pack_chunks(const PackK& k) { return (long long)k.n_taps * k.mtiles * k.kctot * 1024; }
+}  // namespace
+
 extern "C" int unet_conv1d_pack(int32_t dtype, const float* w, int64_t tap_stride, int64_t row_stride,
                                 int64_t col_stride, int32_t n_taps, const int32_t* tap_src_host,
                                 int32_t row_lo, int32_t rows, int32_t col_lo, int32_t c1, int32_t c2,
                                 void* packed, void* stream) {
   UNET_REQUIRE(dtype == UNET_BF16 || dtype == UNET_F32, "pack: bad dtype %d", dtype);
-  UNET_REQUIRE(n_taps > 0 && n_taps <= UNET_MAX_TAPS && rows > 0 && c1 > 0 && c2 >= 0, "pack: bad sizes");
-  UNET_REQUIRE(w && packed && aligned16(packed), "pack: null or misaligned pointer");
   PackK k;
-  k.w = w; k.ts = tap_stride; k.rs = row_stride; k.cs = col_stride;
-  k.n_taps = n_taps; k.row_lo = row_lo; k.rows = rows; k.col_lo = col_lo; k.c1 = c1; k.c2 = c2;
-  k.kc1 = kchunks(dtype, c1); k.kctot = k.kc1 + (c2 > 0 ? kchunks(dtype, c2) : 0);
-  k.mtiles = cdiv(rows, BM);
-  for (int j = 0; j < n_taps; ++j) k.tap_src[j] = tap_src_host ? tap_src_host[j] : j;
-  k.out = static_cast<char*>(packed);
-  const long long total = (long long)n_taps * k.mtiles * k.kctot * 1024;
+  if (fill_pack(&k, dtype, w, tap_stride, row_stride, col_stride, n_taps, tap_src_host, row_lo, rows, col_lo, c1, c2,
+                packed)) return -1;
+  const long long total = pack_chunks(k);
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dtype == UNET_F32) hipLaunchKernelGGL(conv_pack_kernel<true>, dim3(blocks), dim3(256), 0, st, k);
   else hipLaunchKernelGGL(conv_pack_kernel<false>, dim3(blocks), dim3(256), 0, st, k);
   UNET_LAUNCH_CHECK("conv_pack");
+  return 0;
+}
+
+extern "C" int unet_conv1d_pack_multi(int32_t dtype, const UnetPackJob* jobs, int32_t n_jobs, void* stream) {
+  UNET_REQUIRE(dtype == UNET_BF16 || dtype == UNET_F32, "pack_multi: bad dtype %d", dtype);
+  UNET_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= UNET_PACK_MAX_JOBS, "pack_multi: 1..%d jobs per call, got %d",
+               UNET_PACK_MAX_JOBS, n_jobs);
+  PackM m;
+  m.n = n_jobs;
+  long long most = 0;
+  for (int i = 0; i < 3; ++i) {
+    const UnetPackJob& j = jobs[i < n_jobs ? i : 0];     // unused slots repeat job 0 (never run: n guards them)
+    if (fill_pack(&m.k[i], dtype, j.w, j.tap_stride, j.row_stride, j.col_stride, j.n_taps,
+                  j.has_tap_src ? j.tap_src : nullptr, j.row_lo, j.rows, j.col_lo, j.c1, j.c2, j.packed)) return -1;
+    if (i < n_jobs && pack_chunks(m.k[i]) > most) most = pack_chunks(m.k[i]);
+  }
+  const int blocks = (int)((most + 255) / 256 > 8192 ? 8192 : (most + 255) / 256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == UNET_F32) hipLaunchKernelGGL(conv_pack_multi_kernel<true>, dim3(blocks), dim3(256), 0, st, m);
+  else hipLaunchKernelGGL(conv_pack_multi_kernel<false>, dim3(blocks), dim3(256), 0, st, m);
+  UNET_LAUNCH_CHECK("conv_pack_multi");
   return 0;
 }
 

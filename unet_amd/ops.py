@@ -10,6 +10,7 @@ All activations here are "NLC": contiguous ``[N, L, C]`` (channels last), dtype 
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -114,6 +115,7 @@ class ConvGeom:
         rows = sum((l_out - r + self.up - 1) // self.up for r in self.phases)
         return 2.0 * n * c_out * c_in * rows * self.alg_scale
 
+    @functools.lru_cache(maxsize=None)
     def dgrad(self) -> Tuple["ConvGeom", List[int]]:
         """Geometry of the data gradient and, for each of ITS taps, the forward tap it uses."""
         taps = []
@@ -332,6 +334,30 @@ def pack_weights(w: Tensor, dtype: int, *, transpose: bool, tap_src: Optional[Se
     return out
 
 
+def pack_weights_multi(w: Tensor, dtype: int, jobs: Sequence[dict]) -> List[Tensor]:
+    """Several ``pack_weights`` images of one weight tensor in ONE launch (``jobs``: the keyword arguments of each)."""
+    lib = _lib.load()
+    if not 1 <= len(jobs) <= _lib.PACK_MAX_JOBS:
+        raise ValueError(f"1..{_lib.PACK_MAX_JOBS} images per launch, got {len(jobs)}")
+    arr = (_lib.PackJob * len(jobs))()
+    outs = []
+    ts, s1, s2 = w.stride()
+    for a, j in zip(arr, jobs):
+        out = torch.empty(lib.unet_conv1d_packed_bytes(dtype, j["n_taps"], j["rows"], j["c1"], j["c2"]),
+                          dtype=torch.uint8, device=w.device)
+        outs.append(out)
+        a.w, a.tap_stride = w.data_ptr(), ts
+        a.row_stride, a.col_stride = (s2, s1) if j["transpose"] else (s1, s2)
+        a.n_taps, a.has_tap_src = j["n_taps"], int(j["tap_src"] is not None)
+        if j["tap_src"] is not None:
+            for t, v in enumerate(j["tap_src"]):
+                a.tap_src[t] = v
+        a.row_lo, a.rows, a.col_lo, a.c1, a.c2 = j["row_lo"], j["rows"], 0, j["c1"], j["c2"]
+        a.packed = out.data_ptr()
+    check(lib.unet_conv1d_pack_multi(dtype, arr, len(jobs), _stream()), "unet_conv1d_pack_multi")
+    return outs
+
+
 def conv_forward_raw(geom: ConvGeom, x1: Tensor, x2: Optional[Tensor], w_packed: Tensor, bias: Optional[Tensor],
                      res: Optional[Tensor], l_out: int, c_out: int, act: int = 0, out: Optional[Tensor] = None,
                      want_stats: bool = False) -> Tensor:
@@ -378,13 +404,19 @@ def conv_wgrad_raw(geom: ConvGeom, x1: Tensor, x2: Optional[Tensor], dy: Tensor,
     return dw
 
 
-def conv_dgrad_raw(geom: ConvGeom, wf: Tensor, dy: Tensor, l_in: int, row_lo: int, rows: int,
-                   res: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
-    """dx[:, :, row_lo:row_lo+rows] of the conv (wf: fp32 [J, Cout, Ctot]); ``res`` is added in the epilogue, which
-    is how a second gradient path into the same tensor is merged without an extra pass."""
-    gd, src = geom.dgrad()
+def _dgrad_pack_job(geom: ConvGeom, wf: Tensor, row_lo: int, rows: int) -> dict:
     j, c_out, _ = wf.shape
-    wp = pack_weights(wf, _dt(dy), transpose=True, tap_src=src, n_taps=j, row_lo=row_lo, rows=rows, c1=c_out, c2=0)
+    return dict(transpose=True, tap_src=geom.dgrad()[1], n_taps=j, row_lo=row_lo, rows=rows, c1=c_out, c2=0)
+
+
+def conv_dgrad_raw(geom: ConvGeom, wf: Tensor, dy: Tensor, l_in: int, row_lo: int, rows: int,
+                   res: Optional[Tensor] = None, out: Optional[Tensor] = None, wp: Optional[Tensor] = None) -> Tensor:
+    """dx[:, :, row_lo:row_lo+rows] of the conv (wf: fp32 [J, Cout, Ctot]); ``res`` is added in the epilogue, which
+    is how a second gradient path into the same tensor is merged without an extra pass.  ``wp``: the transposed
+    packed image when the caller already has it (ConvFn packs it beside the forward image)."""
+    gd, _ = geom.dgrad()
+    if wp is None:
+        wp = pack_weights(wf, _dt(dy), **_dgrad_pack_job(geom, wf, row_lo, rows))
     return conv_forward_raw(gd, dy, None, wp, None, res, l_in, rows, out=out)
 
 
@@ -399,6 +431,13 @@ _BIAS_HINT = {}
 BIAS_HINT_HITS = 0          # diagnostic: how many conv bias gradients came from a hand-off
 
 
+def _ver(t: Tensor) -> int:
+    try:
+        return t._version
+    except RuntimeError:       # inference tensors keep no version counter (and cannot be written in place either)
+        return -1
+
+
 EPILOGUE_STATS = os.environ.get("UNET_EPILOGUE_STATS", "1") != "0"   # 0: separate statistics pass (A/B measurements)
 _STATS_HINT = {}
 
@@ -407,7 +446,7 @@ def _offer_stats(y: Tensor, s1p: Tensor, s2p: Tensor):
     """Same hand-off for BatchNorm statistics: the conv that wrote ``y`` also wrote its per-tile sum / sum of squares."""
     if len(_STATS_HINT) > 64:
         _STATS_HINT.clear()
-    _STATS_HINT[id(y)] = (weakref.ref(y), s1p, s2p)
+    _STATS_HINT[id(y)] = (weakref.ref(y), s1p, s2p, _ver(y))
 
 
 STATS_HINT_HITS = 0          # diagnostic: how many BatchNorm statistics came from a conv epilogue
@@ -416,7 +455,9 @@ STATS_HINT_HITS = 0          # diagnostic: how many BatchNorm statistics came fr
 def _take_stats(y: Tensor):
     global STATS_HINT_HITS
     h = _STATS_HINT.pop(id(y), None)
-    if h is not None and h[0]() is y and h[1].shape[0] == y.shape[0] and h[1].shape[2] == y.shape[2]:
+    # the same tensor object, not written to since the conv (an in-place op in between would make the sums stale)
+    if (h is not None and h[0]() is y and h[3] == _ver(y) and h[1].shape[0] == y.shape[0]
+            and h[1].shape[2] == y.shape[2]):
         STATS_HINT_HITS += 1
         return h[1], h[2]
     return None
@@ -425,14 +466,18 @@ def _take_stats(y: Tensor):
 def _offer_colsum(dy: Tensor, parts: Tensor):
     if len(_BIAS_HINT) > 64:
         _BIAS_HINT.clear()
-    _BIAS_HINT[id(dy)] = (weakref.ref(dy), parts)
+    _BIAS_HINT[id(dy)] = (weakref.ref(dy), parts, _ver(dy))
 
 
 def _take_colsum(dy: Tensor) -> Optional[Tensor]:
     h = _BIAS_HINT.pop(id(dy), None)
-    if h is not None and h[0]() is dy and h[1].shape[0] == dy.shape[0] and h[1].shape[2] == dy.shape[2]:
+    if (h is not None and h[0]() is dy and h[2] == _ver(dy) and h[1].shape[0] == dy.shape[0]
+            and h[1].shape[2] == dy.shape[2]):
         return h[1]
     return None
+
+
+DUAL_PACK = os.environ.get("UNET_DUAL_PACK", "1") != "0"     # 0: one pack launch per image (A/B measurements)
 
 
 class ConvFn(torch.autograd.Function):
@@ -453,7 +498,25 @@ class ConvFn(torch.autograd.Function):
         wf = w.detach()
         if wf.dtype != torch.float32:
             wf = wf.float()
-        wp = pack_weights(wf, dt, transpose=False, tap_src=None, n_taps=j, row_lo=0, rows=c_out, c1=c1, c2=c2)
+        # the forward image and the transposed images the data gradients will read, in one launch: the weights do
+        # not change between this call and backward (save_for_backward checks that), and a pack is launch-bound
+        jobs = [dict(transpose=False, tap_src=None, n_taps=j, row_lo=0, rows=c_out, c1=c1, c2=c2)]
+        ctx.wp_d1 = ctx.wp_d2 = None
+        want_d1 = DUAL_PACK and ctx.needs_input_grad[0]
+        want_d2 = DUAL_PACK and x2 is not None and ctx.needs_input_grad[1]
+        if want_d1:
+            jobs.append(_dgrad_pack_job(geom, wf, 0, c1))
+        if want_d2:
+            jobs.append(_dgrad_pack_job(geom, wf, c1, c2))
+        if len(jobs) > 1:
+            imgs = pack_weights_multi(wf, dt, jobs)
+            wp = imgs[0]
+            if want_d1:
+                ctx.wp_d1 = imgs[1]
+            if want_d2:
+                ctx.wp_d2 = imgs[-1]
+        else:
+            wp = pack_weights(wf, dt, **jobs[0])
         b = _f32c(bias) if bias is not None else None
         y = conv_forward_raw(geom, x1, x2, wp, b, res, l_out, c_out, want_stats=want_stats)
         ctx.geom, ctx.l_out = geom, l_out
@@ -486,9 +549,9 @@ class ConvFn(torch.autograd.Function):
             if ctx.w_dtype != torch.float32:
                 dw = dw.to(ctx.w_dtype)
         if ctx.needs_input_grad[0]:
-            dx1 = conv_dgrad_raw(geom, wf, dy, l_in, 0, c1)
+            dx1 = conv_dgrad_raw(geom, wf, dy, l_in, 0, c1, wp=ctx.wp_d1)
         if ctx.has_x2 and ctx.needs_input_grad[1]:
-            dx2 = conv_dgrad_raw(geom, wf, dy, l_in, c1, c2)
+            dx2 = conv_dgrad_raw(geom, wf, dy, l_in, c1, c2, wp=ctx.wp_d2)
         return dx1, dx2, dw, db, dres, None, None, None
 
 
