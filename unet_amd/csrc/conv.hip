@@ -577,10 +577,25 @@ __global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_192(const ConvK p
 // its list of 256(co) x 128(pos) output tiles as one continuous stream of (two weight tiles, input chunk) stages
 // through a 3-deep LDS ring filled by buffer_load ... lds, with counted s_waitcnt vmcnt(N) and raw s_barrier so
 // that two stages (96 KiB per CU) stay in flight across barriers, tile boundaries and epilogues.  Every wave
-// issues exactly 6 loads per stage and 16 stores per tile, which is what makes the counts exact (CDNA4 counts
+// issues exactly 6 loads per stage and 8 stores per tile, which is what makes the counts exact (CDNA4 counts
 // loads and stores on one counter).  The 256-channel tile halves the input bytes streamed per FLOP, which is
 // what bounds these convs (L2 -> LDS bandwidth), relative to the 128 x 128 tile of the tap-loop kernel.
 // ---------------------------------------------------------------------------------------------
+// Lane (l15, lq) of an accumulator tile pair holds channels 16*t + 4*lq + r (t = 0, 1: registers a, b; r packed as two
+// bf16 pairs).  Returns the 8 consecutive channels 8*lq .. 8*lq + 7 of the same position instead, by exchanging 16-lane
+// rows between the two registers (v_permlane32_swap, then v_permlane16_swap; rows are the lq groups).
+__device__ __forceinline__ u32x4 quad_regroup(const u32x2 a, const u32x2 b) {
+  u32x4 w;
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    const u32x2 t = __builtin_amdgcn_permlane32_swap(a[pp], b[pp], false, false);   // [a0 a1 b0 b1], [a2 a3 b2 b3]
+    const u32x2 u = __builtin_amdgcn_permlane16_swap(t[0], t[1], false, false);     // [a0 a2 b0 b2], [a1 a3 b1 b3]
+    w[pp] = u[0];
+    w[2 + pp] = u[1];
+  }
+  return w;
+}
+
 constexpr int ST_D = 3;                       // ring depth
 constexpr int ST_THREADS = 512;               // 8 waves: 4 (output-channel groups of 64) x 2 (position halves)
 constexpr int ST_BM = 256;                    // output channels per tile = two packed 128-row weight tiles
@@ -696,7 +711,7 @@ __global__ __launch_bounds__(ST_THREADS, 1) void conv_stream_kernel(const ConvK 
     // registers) multiplies while the first half of stage g is read from LDS, and vice versa, so no LDS read
     // latency is exposed between barriers.  A tile's epilogue therefore runs one step after its last stage.
     auto epilogue = [&](int tile) {
-      // + bias, bf16, 16 buffer stores per wave (rows / channels outside the tensor are dropped by the range
+      // + bias, bf16, 8 buffer stores per wave (rows / channels outside the tensor are dropped by the range
       // check, so the store COUNT is the same for every wave and tile)
       int mt, n, m0;
       decode(tile, mt, n, m0);
@@ -704,15 +719,25 @@ __global__ __launch_bounds__(ST_THREADS, 1) void conv_stream_kernel(const ConvK 
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int m = m0 + wn * (BN / 2) + ni * 16 + l15;
+        u32x2 o[4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
           const int co = mt * ST_BM + wm * 64 + mi * 16 + lq * 4;
           const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + co);
-          bf16x4 o;
+          bf16x4 v;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (__bf16)(acc[mi][ni][r] + bv[r]);
+          for (int r = 0; r < 4; ++r) v[r] = (__bf16)(acc[mi][ni][r] + bv[r]);
+          o[mi] = __builtin_bit_cast(u32x2, v);
+        }
+        // An accumulator lane holds 4 channels of 4 tiles (8-byte stores, 32 contiguous bytes per row and
+        // instruction).  Two lane-row swaps per register pair regroup them into 8 consecutive channels per lane:
+        // 16-byte stores, 64 contiguous bytes per row and instruction, half as many store instructions.
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const u32x4 w = quad_regroup(o[2 * h], o[2 * h + 1]);
+          const int co = mt * ST_BM + wm * 64 + h * 32 + lq * 8;
           const unsigned voff = (m < p.l_out && co < p.c_out) ? (unsigned)((m * p.y_ld + co) * 2) : OOB;
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), ysrd, voff, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(w, ysrd, voff, 0, 0);
         }
       }
       zero_acc();
@@ -728,11 +753,11 @@ __global__ __launch_bounds__(ST_THREADS, 1) void conv_stream_kernel(const ConvK 
     bf16x8 a0[4], b0[NI], a1[4], b1[NI];
     for (int g = 0; g < total; ++g) {
       // stage g must have landed; the stage requested after it (6 loads per wave) may stay in flight -- plus, for
-      // the two steps after a tile epilogue, that tile's 16 stores, which are younger than the stages that were in
+      // the two steps after a tile epilogue, that tile's 8 stores, which are younger than the stages that were in
       // flight when they were issued (loads and stores share the counter and retire in order)
       const int rem = total - 1 - g;
       if (rem >= 1) {
-        if (after > 0) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+        if (after > 0) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1734,8 +1759,8 @@ int conv_fwd_impl(const UnetConvDesc* d, const void* x1, const void* x2, const v
     // single-tap convs with enough K-chunks: the persistent streaming kernel (deep LDS ring)
     const char* envs = getenv("UNET_CONV_NOSTREAM");
     const bool stream = v2 && !(envs && atoi(envs) == 1) && d->n_taps == 1 && d->up == 1 && d->stride == 1 && d->c2 == 0 &&
-                        k.kctot >= 3 && d->c_out <= ST_MAXC && d->c_out % 4 == 0 && !res && d->act == UNET_ACT_NONE &&
-                        k.y_vec && bn == 128 && (long long)d->l_out * d->y_ld * 2 < lim;
+                        k.kctot >= 3 && d->c_out <= ST_MAXC && d->c_out % 8 == 0 && !res && d->act == UNET_ACT_NONE &&
+                        vec_ok(y, d->y_ld, d->y_ns, 2) && bn == 128 && (long long)d->l_out * d->y_ld * 2 < lim;
     if (stream) { g_last_variant = UNET_VARIANT_FWD_STREAM; return launch_stream(k, st); }
     if (v2 && bn == 128) {
       // 192 positions per tile (2/3 of the weight bytes and LDS-DMA instructions per FLOP) for many-tap convs when
