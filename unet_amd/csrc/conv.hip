@@ -751,6 +751,8 @@ __global__ __launch_bounds__(ST_THREADS, 1) void conv_stream_kernel(const ConvK 
 
     int c_tile = 0, c_kc = 0, slot = 0, after = 0;
     bf16x8 a0[4], b0[NI], a1[4], b1[NI];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a1[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; b1[i] = a1[i]; }
     for (int g = 0; g < total; ++g) {
       // stage g must have landed; the stage requested after it (6 loads per wave) may stay in flight -- plus, for
       // the two steps after a tile epilogue, that tile's 8 stores, which are younger than the stages that were in
@@ -767,22 +769,37 @@ __global__ __launch_bounds__(ST_THREADS, 1) void conv_stream_kernel(const ConvK 
       if (g + ST_D - 1 < total) issue_slot(slot == 0 ? ST_D - 1 : slot - 1);
 
       const int so = slot * ST_SLOT;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) a0[mi] = *reinterpret_cast<const bf16x8*>(smem + a_addr[0][mi] + so);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) b0[ni] = *reinterpret_cast<const bf16x8*>(smem + b_addr[0] + so + ni * 2048);
-      if (g > 0) {
-        mma(a1, b1);                      // second half of stage g-1
-        if (c_kc == 0) {                  // ... which closed a tile
-          epilogue(c_tile - 1);
-          after = 2;
-        }
+      mma(a1, b1);                        // second half of stage g-1 (zeros at g == 0)
+      // one fragment read per two MFMAs: the eight waves' reads spread over the block instead of arriving as a burst
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g > 0 && c_kc == 0) {           // ... which closed a tile
+        epilogue(c_tile - 1);
+        after = 2;
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) a1[mi] = *reinterpret_cast<const bf16x8*>(smem + a_addr[1][mi] + so);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) b1[ni] = *reinterpret_cast<const bf16x8*>(smem + b_addr[1] + so + ni * 2048);
       mma(a0, b0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_barrier(0);
       slot = slot + 1 == ST_D ? 0 : slot + 1;
       if (++c_kc == kct) { c_kc = 0; ++c_tile; }
     }
