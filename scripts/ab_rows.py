@@ -1,7 +1,7 @@
 """Same-process A/B of the row-streaming kernels of two builds of libunet_hip.so (raw C-ABI launches, interleaved
 rounds, HIP events; config-B tensor shapes, 64 windows, bf16).
 
-    python scripts/ab_rows.py unet_amd/libunet_hip_A.so unet_amd/libunet_hip.so
+    python scripts/ab_rows.py unet_amd/libunet_hip_A.so unet_amd/libunet_hip.so [substring of the case names to run]
 """
 import ctypes as C
 import os
@@ -55,7 +55,10 @@ def main():
             ("gated_add_fwd", 3, lambda L: L.unet_gated_add_fwd(0, P(y), P(dz), P(a), P(o1), n, rows, c, st)),
             ("gated_add_bwd+sum", 3, lambda L: L.unet_gated_add_bwd(0, P(y), P(dz), P(a), P(o1), P(p1), P(p2), n, rows, c, st)),
         ]
+        only = sys.argv[3] if len(sys.argv) > 3 else ""
         for name, touches, fn in cases:
+            if only not in name:
+                continue
             best = [1e9, 1e9]
             for rnd in range(4):
                 for i in (0, 1, 1, 0):
