@@ -247,7 +247,10 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    if not args.no_kernel_timing and graphed is None:
+    # per-launch HIP events inside the timed region cost ~0.25 ms per step; a data-parallel run (whose per-N values the
+    # driver turns into scaling efficiency against the graph-replayed N = 1 run) takes them after the region instead
+    in_region = not args.no_kernel_timing and graphed is None and world == 1 and not args.dp_selftest
+    if in_region:
         ops.PROFILE = []
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
@@ -260,12 +263,15 @@ def main():
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
     timing_mode = "HIP events around every conv launch inside the timed region (eager launches)"
-    if graphed is not None and not args.no_kernel_timing:
+    if not in_region and not args.no_kernel_timing:
         # A replayed HIP graph has no host-visible launch boundaries, so the per-kernel durations are taken
         # from eager launches of the SAME step (same tensors, same kernels, same stream) right after the timed
         # region; profiles/ holds the rocprofv3 summary of the graph replay itself for cross-checking.
         ops.PROFILE = []
         for _ in range(min(3, args.steps)):
+            if graphed is None:
+                step()            # every rank runs the same full step (its collectives included)
+                continue
             model.zero_grad(set_to_none=True)
             if enc is not None:
                 enc.zero_grad(set_to_none=True)
@@ -273,7 +279,8 @@ def main():
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
         prof_steps = min(3, args.steps)
-        timing_mode = "HIP events around every conv launch, eager launches of the same step right after the graph-replayed timed region"
+        timing_mode = ("HIP events around every conv launch, eager launches of the same step right after the "
+                       + ("graph-replayed" if graphed is not None else "data-parallel") + " timed region")
     else:
         prof_steps = args.steps
     if world > 1:
