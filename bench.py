@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--cpu-windows", type=int, default=8, help="windows per CPU-baseline step (1 warm-up + 3 timed steps "
                     "at each thread count)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--optimizer", default="native", choices=["native", "torch"],
+                    help="native: unet_amd.optim.ClipAdamW (clip + AdamW in three HIP launches); torch: "
+                         "clip_grad_norm_ + torch.optim.AdamW(fused=True)")
     ap.add_argument("--conditioning", default="odor_onehot", choices=["odor_onehot", "spectro_temporal"],
                     help="spectro_temporal: the SpectroTemporalEncoder (train.py --conditioning default) runs inside the "
                          "step and trains with the model; the headline config is odor_onehot")
@@ -188,8 +191,18 @@ def main():
         enc.eval()                                                         # train.py:1410-1411
         broadcast_parameters(enc)
         groups.append({"params": list(enc.parameters()), "name": "cond_encoder"})  # train.py:2225-2227
-    opt = torch.optim.AdamW(groups, lr=2e-4, betas=(0.7595905764360957, 0.920298282605139),
-                            weight_decay=0.0, fused=True, capturable=not args.eager)  # train.py:183-193
+    BETAS = (0.7595905764360957, 0.920298282605139)                         # train.py:183-193
+
+    def make_optimizer(capturable):
+        if args.optimizer == "native":     # K17: clip 5.0 + AdamW as three HIP launches (the encoder keeps its own clip)
+            from unet_amd.optim import ClipAdamW
+            groups[0]["max_grad_norm"] = 5.0
+            for grp in groups[1:]:
+                grp["max_grad_norm"] = None
+            return ClipAdamW(groups, lr=2e-4, betas=BETAS, weight_decay=0.0)
+        return torch.optim.AdamW(groups, lr=2e-4, betas=BETAS, weight_decay=0.0, fused=True, capturable=capturable)
+
+    opt = make_optimizer(not args.eager)
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     B = args.batch
@@ -217,8 +230,7 @@ def main():
             traceback.print_exc()
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}); running eagerly", file=sys.stderr)
             graphed = None
-            opt = torch.optim.AdamW(groups, lr=2e-4, betas=(0.7595905764360957, 0.920298282605139),
-                                    weight_decay=0.0, fused=True)
+            opt = make_optimizer(False)
     if graphed is None:
         reducer = BucketedGradAllReduce(model.parameters(), force=args.dp_selftest)
 
@@ -232,7 +244,8 @@ def main():
         loss = loss_fn(model(ob, ids, cond_emb=enc(ob)) if enc is not None else model(ob, ids), tgt)
         loss.backward()
         reducer.finish()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)  # train.py:1553 GRAD_CLIP
+        if not getattr(opt, "clips_gradients", False):
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)  # train.py:1553 GRAD_CLIP
         if enc is not None:                                      # train.py:1556-1558
             torch.nn.utils.clip_grad_norm_(enc.parameters(), 5.0)
             coalesced_grad_mean(list(enc.parameters()))
@@ -298,7 +311,7 @@ def main():
         "config": {"workload": wl_descr + f", {c_in}ch x {T} windows, {B} windows/GPU, fwd + L1[500:4500] + bwd + "
                                "grad all-reduce + clip 5.0 + AdamW", "windows_per_gpu": B, "params": n_params,
                    "parallelism": f"dp{world}" + (" (one-rank RCCL group, collectives forced)" if args.dp_selftest else ""), "launch": mode, "conditioning": args.conditioning,
-                   "attention": args.attention},
+                   "attention": args.attention, "optimizer": args.optimizer},
         "final_loss": float(loss.item()), "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
         "ms_each_step": [round(evs[i].elapsed_time(evs[i + 1]), 2) for i in range(args.steps)],
         "model_tflops_algorithmic": value * 3 * gflop_fwd / 1e3,

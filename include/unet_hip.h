@@ -418,6 +418,37 @@ int unet_noise_augment(int32_t dtype, const void* x, const void* gauss, const vo
                        const float* line_amp, const float* line_phase, float line_hz, float sample_rate,
                        int32_t n, int32_t c, int32_t t, void* y, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer step (csrc/optim.hip): torch.nn.utils.clip_grad_norm_(params, max_norm) followed by
+ * torch.optim.AdamW(...).step() (train.py:1553,1559; AdamW arguments train.py:183-193,2214-2241), on the device end to
+ * end (no host read of the norm; capturable in a HIP graph).
+ *
+ * The moments of a parameter group live in two flat fp32 buffers; tensor t owns elements [4*start4[t], 4*start4[t] +
+ * numel[t]).  start4 (n_tensors + 1 entries, the last = end of the range), numel and p_ptrs are DEVICE arrays built once
+ * by the caller; the gradient pointers are a HOST array (they change every step) of n_tensors <= UNET_OPT_MAX_TENSORS
+ * entries, null = "no gradient this step" (that parameter is skipped, as torch does).  flat_elements = 4 * (start4[n] -
+ * start4[0]).  Larger groups are processed as several calls over consecutive sub-tables, with their partial sums side
+ * by side in one `partial` array (unet_opt_blocks(flat_elements) floats per call) and ONE prepare call over all of them.
+ *
+ *   unet_grad_sqnorm         partial[b] = sum of g^2 over block b's slice of the flat range; step_t[t] += 1 for every
+ *                            tensor of the call that has a gradient (one fp32 counter per tensor, as torch keeps them)
+ *   unet_clip_adamw_prepare  coef[0] = clip = min(1, max_norm / (||g|| + 1e-6)) (1 if max_norm <= 0);
+ *                            coef[3] = ||g||;  coef[4] = lr (read from the device scalar *lr); coef holds 8 floats
+ *   unet_clip_adamw_apply    g' = clip * g;  p *= 1 - lr * weight_decay;  m = beta1 m + (1 - beta1) g';
+ *                            v = beta2 v + (1 - beta2) g'^2;
+ *                            p -= lr / (1 - beta1^step_t) * m / (sqrt(v) / sqrt(1 - beta2^step_t) + eps)
+ * The clipped gradient itself is not written back. */
+#define UNET_OPT_MAX_TENSORS 256
+int32_t unet_opt_blocks(int64_t flat_elements);
+int unet_grad_sqnorm(const float* const* grads_host, int32_t n_tensors, const uint32_t* start4, const uint32_t* numel,
+                     int64_t flat_elements, float* partial, float* step_t, void* stream);
+int unet_clip_adamw_prepare(const float* partial, int32_t blocks, float max_norm, const float* lr, float* coef,
+                            void* stream);
+int unet_clip_adamw_apply(const float* const* grads_host, int32_t n_tensors, float* const* p_ptrs,
+                          const uint32_t* start4, const uint32_t* numel, int64_t flat_elements, float* m_flat,
+                          float* v_flat, const float* coef, const float* step_t, float beta1, float beta2, float eps,
+                          float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,7 @@ class PackJob(C.Structure):
 
 
 PACK_MAX_JOBS = 3
+OPT_MAX_TENSORS = 256
 
 
 class ConvDesc(C.Structure):
@@ -67,6 +68,11 @@ _SIGNATURES = {
     "unet_conv1d_pack": (C.c_int, [_i32, _vp, _i64, _i64, _i64, _i32, C.POINTER(_i32), _i32, _i32, _i32,
                                    _i32, _i32, _vp, _vp]),
     "unet_conv1d_pack_multi": (C.c_int, [_i32, C.POINTER(PackJob), _i32, _vp]),
+    "unet_opt_blocks": (_i32, [_i64]),
+    "unet_grad_sqnorm": (C.c_int, [C.POINTER(C.c_void_p), _i32, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "unet_clip_adamw_prepare": (C.c_int, [_vp, _i32, C.c_float, _vp, _vp, _vp]),
+    "unet_clip_adamw_apply": (C.c_int, [C.POINTER(C.c_void_p), _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, C.c_float,
+                                         C.c_float, C.c_float, C.c_float, _vp]),
     "unet_conv1d_fwd": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "unet_conv1d_stats_max_parts": (_i32, [C.POINTER(ConvDesc)]),
     "unet_conv1d_fwd_stats": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp]),

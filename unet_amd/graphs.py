@@ -77,7 +77,7 @@ class GraphedTrainStep:
             return loss
 
         def update():
-            if self.clip is not None:
+            if self.clip is not None and not getattr(self.opt, "clips_gradients", False):   # optim.ClipAdamW clips inside step()
                 torch.nn.utils.clip_grad_norm_(self.model_params, self.clip)
             self.opt.step()
 
@@ -128,7 +128,7 @@ class GraphedTrainStep:
             loss = loss_fn(out, *self.static_tg)
             loss.backward()                      # bucket hooks fire in here: pack + async all-reduce per bucket
             self.reducer.finish()                # the only wait on the collectives
-            if self.clip is not None:
+            if self.clip is not None and not getattr(self.opt, "clips_gradients", False):
                 torch.nn.utils.clip_grad_norm_(self.model_params, self.clip)
             self.opt.step()
             return loss

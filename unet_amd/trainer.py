@@ -46,8 +46,11 @@ class Trainer:
                  weight_l1: float = 1.0, grad_clip: float = GRAD_CLIP, compute_dtype: Optional[torch.dtype] = torch.bfloat16,
                  use_graph: bool = False, bucket_bytes: int = 64 << 20, nan_check_every: int = 50, process_group=None,
                  cond_encoder: Optional[torch.nn.Module] = None, noise_augmentor: Optional[torch.nn.Module] = None,
-                 loss_fn: Optional[Callable] = None, normalize_target: Optional[Callable] = None):
-        """``loss_fn(pred, target)`` / ``normalize_target(target)`` default to the reference's step
+                 loss_fn: Optional[Callable] = None, normalize_target: Optional[Callable] = None,
+                 optimizer: Optional[str] = None):
+        """``optimizer``: "native" (``optim.ClipAdamW``: clip + AdamW as three HIP launches, the default on a GPU) or
+        "torch" (``clip_grad_norm_`` + ``torch.optim.AdamW``, the default on CPU).
+        ``loss_fn(pred, target)`` / ``normalize_target(target)`` default to the reference's step
         (``weight_l1 * l1_crop_loss`` on the HIP kernels after ``per_channel_normalize``); the host-logic tests
         pass plain torch callables so that the data-parallel protocol runs on CPU under gloo."""
         self.model = model
@@ -70,8 +73,19 @@ class Trainer:
             groups.append({"params": list(cond_encoder.parameters()), "lr": lr, "name": "cond_encoder"})  # train.py:2225-2227
         self.weight_l1, self.grad_clip = weight_l1, grad_clip
         self.use_graph = use_graph
-        self.opt = torch.optim.AdamW(groups, lr=lr, betas=betas, weight_decay=weight_decay, fused=True,
-                                     capturable=use_graph)
+        if optimizer is None:
+            optimizer = "native" if next(model.parameters()).is_cuda else "torch"
+        if optimizer == "native":     # K17: clip + AdamW in three HIP launches (unet_amd/optim.py); the model's clip runs
+            from .optim import ClipAdamW   # inside step(), the encoder's stays in front of its gradient average
+            groups[0]["max_grad_norm"] = grad_clip
+            for g in groups[1:]:
+                g["max_grad_norm"] = None
+            self.opt = ClipAdamW(groups, lr=lr, betas=betas, weight_decay=weight_decay)
+        elif optimizer == "torch":
+            self.opt = torch.optim.AdamW(groups, lr=lr, betas=betas, weight_decay=weight_decay, fused=True,
+                                         capturable=use_graph)
+        else:
+            raise ValueError(f"optimizer must be 'native' or 'torch', got {optimizer!r}")
         self.reducer = None if use_graph else BucketedGradAllReduce(model.parameters(), bucket_bytes, process_group)
         self._graphed = None
         self._bucket_bytes = bucket_bytes
@@ -141,7 +155,8 @@ class Trainer:
                 raise ValueError("NaN/Inf detected in loss")      # train.py:1543-1544: before backward, weights intact
             loss.backward()
             self.reducer.finish()
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip)
+            if not getattr(self.opt, "clips_gradients", False):
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip)
             if self.cond_encoder is not None:                      # train.py:1556-1558: clip per rank, then average
                 torch.nn.utils.clip_grad_norm_(self.cond_encoder.parameters(), self.grad_clip)
                 coalesced_grad_mean(list(self.cond_encoder.parameters()), self.pg)
