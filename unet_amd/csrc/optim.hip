@@ -44,6 +44,21 @@ __global__ __launch_bounds__(OPT_THREADS) void grad_sqnorm_kernel(const GradPtrs
   float s = 0.f;
   if (lo < hi) {
     int t = find_tensor(start4, n, lo);
+    const float* g0 = gp.g[t];
+    // the usual case -- the block's whole slice inside one tensor, whole float4s: all eight loads of a thread in flight
+    if (hi <= start4[t + 1] && (hi - start4[t]) * 4 <= numel[t] && !(reinterpret_cast<uintptr_t>(g0) & 15)) {
+      if (g0) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(g0) + (lo - start4[t]);
+        f32x4 v[OPT_CH4 / OPT_THREADS];
+#pragma unroll
+        for (int u = 0; u < OPT_CH4 / OPT_THREADS; ++u) {
+          const uint32_t k = threadIdx.x + u * OPT_THREADS;
+          v[u] = lo + k < hi ? src[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < OPT_CH4 / OPT_THREADS; ++u) s += v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3];
+      }
+    } else
     for (uint32_t f4 = lo + threadIdx.x; f4 < hi; f4 += OPT_THREADS) {
       while (f4 >= start4[t + 1]) ++t;
       const float* g = gp.g[t];
