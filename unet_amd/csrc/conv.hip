@@ -293,7 +293,9 @@ __global__ __launch_bounds__(THREADS, 2) void conv_fwd_kernel(const ConvK p) {
 // ---------------------------------------------------------------------------------------------
 constexpr int F2_MAXP = 12;   // x-tile pieces (8 rows of 128 B) per wave: halo tiles up to 384 rows
 
-template <int BN>
+// HALF: every K-chunk of the conv holds at most 32 channels (the first conv's Cin = 32): the second k-step of each
+// chunk would multiply zeros and is compiled out (as a run-time flag it cost the other convs 0.3-1.5 %)
+template <int BN, bool HALF = false>
 __device__ __forceinline__ void conv_fwd2_body(const ConvK& p) {
   typedef __bf16 T;
   constexpr int NI = BN / 32;
@@ -430,14 +432,16 @@ __device__ __forceinline__ void conv_fwd2_body(const ConvK& p) {
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    if constexpr (!HALF) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(smem + a_addr[1][mi]);
+      for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(smem + a_addr[1][mi]);
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(smem + b1 + ni * 2048);
+      for (int ni = 0; ni < NI; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(smem + b1 + ni * 2048);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -568,6 +572,8 @@ __device__ __forceinline__ void conv_fwd2_body(const ConvK& p) {
 __global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_128(const ConvK p) { conv_fwd2_body<128>(p); }
 __global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_64(const ConvK p) { conv_fwd2_body<64>(p); }
 __global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_192(const ConvK p) { conv_fwd2_body<192>(p); }
+__global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_128h(const ConvK p) { conv_fwd2_body<128, true>(p); }
+__global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_192h(const ConvK p) { conv_fwd2_body<192, true>(p); }
 
 // ---------------------------------------------------------------------------------------------
 // Streaming kernel for single-tap (1x1) convolutions: FiLM q_proj / out_proj, skip_proj, residual_conv and
@@ -1557,24 +1563,24 @@ void tile_geom(const UnetConvDesc* d, const Phases& ph, int bn, TileGeom* tg) {
 
 template <int BN>
 int launch_fwd2(ConvK& k, int rmax, hipStream_t st) {
-  static bool attr_set = false;
   const int xbytes = ((rmax + 7) / 8) * 1024;
   k.xbytes = xbytes;
   k.xdb = (2 * WTILE_BYTES + 2 * (size_t)xbytes <= 80 * 1024) ? 1 : 0;
   const size_t lds = 2 * WTILE_BYTES + (size_t)xbytes * (k.xdb ? 2 : 1);
-  const void* fn = BN == 192 ? reinterpret_cast<const void*>(&conv_fwd2_kernel_192)
-                 : BN == 128 ? reinterpret_cast<const void*>(&conv_fwd2_kernel_128)
-                             : reinterpret_cast<const void*>(&conv_fwd2_kernel_64);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  // one source of at most 32 channels: the variant without the second k-step (BN 128 / 192)
+  const bool half = BN != 64 && k.c2 == 0 && k.c1 <= 32;
+  void (*kern)(const ConvK) = BN == 192 ? (half ? conv_fwd2_kernel_192h : conv_fwd2_kernel_192)
+                            : BN == 128 ? (half ? conv_fwd2_kernel_128h : conv_fwd2_kernel_128)
+                                        : conv_fwd2_kernel_64;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[half]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     UNET_REQUIRE(e == hipSuccess, "conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    attr_set = true;
+    attr_set[half] = true;
   }
   const long long blocks = (long long)k.mtiles * k.n * (k.ptiles[0] + k.ptiles[1]);
   UNET_REQUIRE(blocks > 0 && blocks < (1ll << 31), "conv: grid of %lld blocks", blocks);
-  if (BN == 192) hipLaunchKernelGGL(conv_fwd2_kernel_192, dim3((unsigned)blocks), dim3(THREADS), lds, st, k);
-  else if (BN == 128) hipLaunchKernelGGL(conv_fwd2_kernel_128, dim3((unsigned)blocks), dim3(THREADS), lds, st, k);
-  else hipLaunchKernelGGL(conv_fwd2_kernel_64, dim3((unsigned)blocks), dim3(THREADS), lds, st, k);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), lds, st, k);
   UNET_LAUNCH_CHECK("conv_fwd2");
   return 0;
 }
