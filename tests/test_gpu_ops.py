@@ -383,3 +383,57 @@ def test_pack_multi_images_equal_single_packs(dtype, stride):
             ops.DUAL_PACK = True
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cin", [8, 24, 32])
+@pytest.mark.parametrize("kind", ["merged", "k7s2", "k3"])
+def test_small_cin_weight_gradient_and_half_chunk_forward(cin, kind):
+    """Convs of at most 32 input channels (the model's first conv) take their own kernel variants: the forward kernel
+    without the zero k-step and the weight-gradient kernel with four taps per group.  Both must give what the regular
+    kernels give (the weight gradient bit for bit: same products, same order) and agree with an fp64 evaluation of
+    the same bf16 operands."""
+    import os
+    from unet_amd import ops
+    torch.manual_seed(7)
+    dev = "cuda"
+    n, l, co = 3, 333, 136
+    if kind == "merged":
+        g0, _ = ops.merged_dilated_taps(7, (1, 4, 16, 32))
+        geom = ops.ConvGeom(g0.offs, g0.phases, 1, 1, g0.alg_scale)
+    elif kind == "k7s2":
+        geom = ops.geom_conv(7, stride=2)
+    else:
+        geom = ops.geom_conv(3)
+    l_out = (l + geom.stride - 1) // geom.stride
+    x = torch.randn(n, l, cin, device=dev).bfloat16()
+    dy = torch.randn(n, l_out, co, device=dev).bfloat16()
+    w = torch.randn(geom.n_taps, co, cin, device=dev) * 0.1
+    dw = ops.conv_wgrad_raw(geom, x, None, dy, co)
+    os.environ["UNET_WGRAD_NOSMALL"] = "1"
+    try:
+        dw_regular = ops.conv_wgrad_raw(geom, x, None, dy, co)
+    finally:
+        del os.environ["UNET_WGRAD_NOSMALL"]
+    assert torch.equal(dw, dw_regular)
+    # fp64 reference: dw[j][co][ci] = sum_{n,m} dy[n,m,co] * x[n, stride*m + off_j, ci]
+    xd, dyd = x.double(), dy.double()
+    ref = torch.zeros(geom.n_taps, co, cin, dtype=torch.float64, device=dev)
+    for j, off in enumerate(geom.offs):
+        m = torch.arange(l_out, device=dev)
+        src = geom.stride * m + off
+        ok = (src >= 0) & (src < l)
+        xs = torch.zeros(n, l_out, cin, dtype=torch.float64, device=dev)
+        xs[:, ok] = xd[:, src[ok]]
+        ref[j] = torch.einsum("nmo,nmi->oi", dyd, xs)
+    assert rel(dw, ref) < 1e-5
+    y = ops.conv(x, w, None, geom, l_out)
+    yr = torch.zeros(n, l_out, co, dtype=torch.float64, device=dev)
+    wq = w.bfloat16().double()
+    for j, off in enumerate(geom.offs):
+        m = torch.arange(l_out, device=dev)
+        src = geom.stride * m + off
+        ok = (src >= 0) & (src < l)
+        xs = torch.zeros(n, l_out, cin, dtype=torch.float64, device=dev)
+        xs[:, ok] = xd[:, src[ok]]
+        yr += torch.einsum("nmi,oi->nmo", xs, wq[j])
+    assert rel(y, yr) < 4e-3

@@ -1102,10 +1102,16 @@ struct Wg2K {
   int g_off[UNET_MAX_TAPS];    // input offset of the first tap
   int g_delta[UNET_MAX_TAPS];  // (off_b - off_a) / stride
   int g_phase[UNET_MAX_TAPS];
+  // small-Cin variant (c1 <= 32): up to FOUR taps per group; taps c, d (or -1) and their row distances from tap a
+  int g_tapc[UNET_MAX_TAPS], g_tapd[UNET_MAX_TAPS], g_deltac[UNET_MAX_TAPS], g_deltad[UNET_MAX_TAPS];
 };
 
-__global__ __launch_bounds__(THREADS, 2) void conv_wgrad2_kernel(const Wg2K p) {
-  typedef __bf16 T;
+// SMALL: at most 32 input channels (the first conv, inc).  With the regular mapping only a quarter of the 128-wide
+// input-channel tile is real and the waves of the upper half (wn = 1) multiply zeros; here a group holds up to four
+// taps, each wave computes two of them (wn = 0: taps a, b; wn = 1: taps c, d) on the 32 real channels (two 16-wide
+// fragments), so a block does a third of the MFMAs for twice the taps.
+template <bool SMALL>
+__device__ __forceinline__ void conv_wgrad2_body(const Wg2K& p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1121,9 +1127,21 @@ __global__ __launch_bounds__(THREADS, 2) void conv_wgrad2_kernel(const Wg2K p) {
   const int split = wg % p.splits;
   const int mt = wg / p.splits;
 
-  const int phase = p.g_phase[grp], off0 = p.g_off[grp], delta = p.g_delta[grp];
-  const bool two = p.g_tapb[grp] >= 0;
-  const int xrows = WG2_BKP + (two ? delta : 0);
+  const int phase = p.g_phase[grp], off0 = p.g_off[grp];
+  constexpr int NI = SMALL ? 2 : 4;
+  // the (up to) two taps of this wave: LDS row distance from tap a, descriptor index (-1: none)
+  const int t0 = (SMALL && wn) ? p.g_tapc[grp] : p.g_tapa[grp];
+  const int t1 = (SMALL && wn) ? p.g_tapd[grp] : p.g_tapb[grp];
+  const int d0 = (SMALL && wn) ? p.g_deltac[grp] : 0;
+  const int delta = (SMALL && wn) ? p.g_deltad[grp] : p.g_delta[grp];
+  const bool one = !SMALL || t0 >= 0;
+  const bool two = t1 >= 0;
+  int dmax = p.g_tapb[grp] >= 0 ? p.g_delta[grp] : 0;
+  if (SMALL) {
+    if (p.g_tapc[grp] >= 0 && p.g_deltac[grp] > dmax) dmax = p.g_deltac[grp];
+    if (p.g_tapd[grp] >= 0 && p.g_deltad[grp] > dmax) dmax = p.g_deltad[grp];
+  }
+  const int xrows = WG2_BKP + dmax;
   const int mcount = p.mcount[phase];
   const int mchunks = (mcount + WG2_BKP - 1) / WG2_BKP;
   const int items = p.n * mchunks;
@@ -1192,13 +1210,16 @@ __global__ __launch_bounds__(THREADS, 2) void conv_wgrad2_kernel(const Wg2K p) {
   for (int half = 0; half < 2; ++half) {
     const int row = lq * 8 + half * 4 + q;
     const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+    const int rowb = row + d0;
+    const int swb = ((rowb & 3) << 2) | ((rowb >> 2) & 3);
     const int rowd = row + delta;
     const int swd = ((rowd & 3) << 2) | ((rowd >> 2) & 3);
+    const int cb = SMALL ? 0 : wn * 64;          // first input channel of this wave's fragments
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       a_addr[half][i] = row * 256 + ((((wm * 64 + i * 16) >> 3) + (pp >> 1)) ^ sw) * 16 + 8 * (pp & 1);
-      b_addr[half][i] = WG2_DY_BYTES + row * 256 + ((((wn * 64 + i * 16) >> 3) + (pp >> 1)) ^ sw) * 16 + 8 * (pp & 1);
-      c_addr[half][i] = WG2_DY_BYTES + rowd * 256 + ((((wn * 64 + i * 16) >> 3) + (pp >> 1)) ^ swd) * 16 + 8 * (pp & 1);
+      b_addr[half][i] = WG2_DY_BYTES + rowb * 256 + ((((cb + i * 16) >> 3) + (pp >> 1)) ^ swb) * 16 + 8 * (pp & 1);
+      c_addr[half][i] = WG2_DY_BYTES + rowd * 256 + ((((cb + i * 16) >> 3) + (pp >> 1)) ^ swd) * 16 + 8 * (pp & 1);
     }
   }
   auto tr_read = [&](int addr) -> bf16x4 {
@@ -1207,10 +1228,11 @@ __global__ __launch_bounds__(THREADS, 2) void conv_wgrad2_kernel(const Wg2K p) {
   };
 
   auto compute = [&](int stage_off) {
+    if (!one) return;                    // SMALL only: a wave whose half of the group holds no tap
 #pragma unroll
     for (int ks = 0; ks < WG2_BKP / 32; ++ks) {
       const int o = stage_off + ks * 32 * 256;
-      bf16x8 a[4], b[4];
+      bf16x8 a[4], b[NI];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -1220,7 +1242,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_wgrad2_kernel(const Wg2K p) {
           for (int e = 0; e < 4; ++e) a[mi][half * 4 + e] = vb[e];
         }
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
           bf16x4 vb = tr_read(b_addr[half][ni] + o);
 #pragma unroll
           for (int e = 0; e < 4; ++e) b[ni][half * 4 + e] = vb[e];
@@ -1229,13 +1251,13 @@ __global__ __launch_bounds__(THREADS, 2) void conv_wgrad2_kernel(const Wg2K p) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
           acc0[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc0[mi][ni], 0, 0, 0);
       if (two) {
 #pragma unroll
         for (int half = 0; half < 2; ++half)
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) {
+          for (int ni = 0; ni < NI; ++ni) {
             bf16x4 vb = tr_read(c_addr[half][ni] + o);
 #pragma unroll
             for (int e = 0; e < 4; ++e) b[ni][half * 4 + e] = vb[e];
@@ -1243,7 +1265,7 @@ __global__ __launch_bounds__(THREADS, 2) void conv_wgrad2_kernel(const Wg2K p) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
+          for (int ni = 0; ni < NI; ++ni)
             acc1[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc1[mi][ni], 0, 0, 0);
       }
     }
@@ -1273,8 +1295,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv_wgrad2_kernel(const Wg2K p) {
   auto store = [&](const f32x4 (&acc)[4][4], int tap) {
     float* slab = p.slab + ((long long)split * p.n_taps + tap) * p.c_out * ctot;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int cl = xc0 + wn * 64 + ni * 16 + l15;  // channel within its source
+    for (int ni = 0; ni < NI; ++ni) {
+      const int cl = xc0 + (SMALL ? 0 : wn * 64) + ni * 16 + l15;  // channel within its source
       if (cl >= xc) continue;
       const int ci = ci_off + cl;
 #pragma unroll
@@ -1287,9 +1309,12 @@ __global__ __launch_bounds__(THREADS, 2) void conv_wgrad2_kernel(const Wg2K p) {
       }
     }
   };
-  store(acc0, p.g_tapa[grp]);
-  if (two) store(acc1, p.g_tapb[grp]);
+  if (one) store(acc0, t0);
+  if (two) store(acc1, t1);
 }
+
+__global__ __launch_bounds__(THREADS, 2) void conv_wgrad2_kernel(const Wg2K p) { conv_wgrad2_body<false>(p); }
+__global__ __launch_bounds__(THREADS, 2) void conv_wgrad2s_kernel(const Wg2K p) { conv_wgrad2_body<true>(p); }
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient of SINGLE-TAP convs with wide channel counts (the FiLM q_proj / out_proj at C >= 512,
@@ -1836,10 +1861,21 @@ int wgrad_splits(const UnetConvDesc* d, const Phases& ph) {
 }  // namespace
 
 namespace {
-// groups of <= 2 taps that can share one input tile: same phase, same (offset mod stride), distance <= 32 rows
-struct WgGroups { int n; int tapa[UNET_MAX_TAPS], tapb[UNET_MAX_TAPS], off[UNET_MAX_TAPS], delta[UNET_MAX_TAPS], phase[UNET_MAX_TAPS]; };
+// groups of taps that can share one input tile: same phase, same (offset mod stride), at most 32 rows from the
+// group's first tap.  Two taps per group; four for the small-Cin variant (conv_wgrad2s_kernel).
+struct WgGroups {
+  int n;
+  int tapa[UNET_MAX_TAPS], tapb[UNET_MAX_TAPS], tapc[UNET_MAX_TAPS], tapd[UNET_MAX_TAPS];
+  int off[UNET_MAX_TAPS], delta[UNET_MAX_TAPS], deltac[UNET_MAX_TAPS], deltad[UNET_MAX_TAPS], phase[UNET_MAX_TAPS];
+};
+
+bool wgrad2_small(const UnetConvDesc* d) {
+  const char* env = getenv("UNET_WGRAD_NOSMALL");
+  return d->c2 == 0 && d->c1 <= 32 && !(env && atoi(env) == 1);
+}
 
 void wgrad_groups(const UnetConvDesc* d, WgGroups* g) {
+  const int per = wgrad2_small(d) ? 4 : 2;
   int order[UNET_MAX_TAPS];
   for (int j = 0; j < d->n_taps; ++j) order[j] = j;
   auto cls = [&](int j) { return ((d->tap_off[j] % d->stride) + d->stride) % d->stride; };
@@ -1853,15 +1889,19 @@ void wgrad_groups(const UnetConvDesc* d, WgGroups* g) {
   g->n = 0;
   for (int i = 0; i < d->n_taps;) {
     const int a = order[i];
-    int b = -1;
-    if (i + 1 < d->n_taps) {
-      const int c = order[i + 1];
-      if (d->tap_phase[c] == d->tap_phase[a] && cls(c) == cls(a) && (d->tap_off[c] - d->tap_off[a]) / d->stride <= 32) b = c;
+    int member[4] = {a, -1, -1, -1}, dl[4] = {0, 0, 0, 0}, cnt = 1;
+    while (cnt < per && i + cnt < d->n_taps) {
+      const int c = order[i + cnt];
+      if (d->tap_phase[c] != d->tap_phase[a] || cls(c) != cls(a) || (d->tap_off[c] - d->tap_off[a]) / d->stride > 32) break;
+      member[cnt] = c;
+      dl[cnt] = (d->tap_off[c] - d->tap_off[a]) / d->stride;
+      ++cnt;
     }
-    g->tapa[g->n] = a; g->tapb[g->n] = b; g->off[g->n] = d->tap_off[a]; g->phase[g->n] = d->tap_phase[a];
-    g->delta[g->n] = b >= 0 ? (d->tap_off[b] - d->tap_off[a]) / d->stride : 0;
-    ++g->n;
-    i += b >= 0 ? 2 : 1;
+    const int k = g->n++;
+    g->tapa[k] = member[0]; g->tapb[k] = member[1]; g->tapc[k] = member[2]; g->tapd[k] = member[3];
+    g->off[k] = d->tap_off[a]; g->phase[k] = d->tap_phase[a];
+    g->delta[k] = dl[1]; g->deltac[k] = dl[2]; g->deltad[k] = dl[3];
+    i += cnt;
   }
 }
 
@@ -2048,17 +2088,21 @@ int wgrad_impl(const UnetConvDesc* d, const void* x1, const void* x2, const void
       const bool v = j < g.n;
       k.g_tapa[j] = v ? g.tapa[j] : 0; k.g_tapb[j] = v ? g.tapb[j] : -1; k.g_off[j] = v ? g.off[j] : 0;
       k.g_delta[j] = v ? g.delta[j] : 0; k.g_phase[j] = v ? g.phase[j] : 0;
+      k.g_tapc[j] = v ? g.tapc[j] : -1; k.g_tapd[j] = v ? g.tapd[j] : -1;
+      k.g_deltac[j] = v ? g.deltac[j] : 0; k.g_deltad[j] = v ? g.deltad[j] : 0;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad2_kernel),
+    const bool small = wgrad2_small(d);
+    void (*kern)(const Wg2K) = small ? conv_wgrad2s_kernel : conv_wgrad2_kernel;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[small]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG2_STAGE);
       UNET_REQUIRE(e == hipSuccess, "conv_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      attr_set = true;
+      attr_set[small] = true;
     }
     const long long blocks = (long long)k.mtiles * k.kttot * splits * g.n;
     UNET_REQUIRE(blocks < (1ll << 31), "conv_wgrad: grid too large");
-    hipLaunchKernelGGL(conv_wgrad2_kernel, dim3((unsigned)blocks), dim3(THREADS), 2 * WG2_STAGE, st, k);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), 2 * WG2_STAGE, st, k);
     UNET_LAUNCH_CHECK("conv_wgrad2");
     const long long cols = (count & 3) ? count : count >> 2;
     int rb = (int)((cols + 255) / 256 > 4096 ? 4096 : (cols + 255) / 256);
