@@ -1919,19 +1919,19 @@ bool wgrad2_ok(const UnetConvDesc* d, const void* x1, const void* x2, const void
   return true;
 }
 
-// the 256 x 256-tile kernel: one tap at unit stride, one source, whole 256-channel tiles, at least four of them
+// the 256 x 256-tile kernel: one tap at unit stride, one source, whole 256-channel tiles
 bool wgrad3_ok(const UnetConvDesc* d) {
   const char* env = getenv("UNET_WGRAD3");
   if (env && atoi(env) == 0) return false;
   return d->dtype == UNET_BF16 && d->n_taps == 1 && d->stride == 1 && d->up == 1 && d->c2 == 0 && d->c1 % 256 == 0 &&
-         d->c_out % 256 == 0 && (long long)(d->c1 / 256) * (d->c_out / 256) >= 4;
+         d->c_out % 256 == 0;
 }
 int wgrad3_splits(const UnetConvDesc* d) {
   // one workgroup per CU: enough splits to give every CU one, never more items than there are
   const long long tiles = (long long)(d->c1 / 256) * (d->c_out / 256);
   const long long items = (long long)d->n * cdiv(d->l_out, WG3_BKP);
-  long long s = (256 + tiles - 1) / tiles;
-  if (s > 64) s = 64;
+  long long s = (256 + tiles - 1) / tiles;       // up to 256 splits for the single 256 x 256 tile of a C = 256 conv:
+  if (s > 256) s = 256;                          // 101 -> 81 us there (64 splits: 146 us, a quarter of the CUs)
   if (s > items) s = items;
   return (int)(s < 1 ? 1 : s);
 }
@@ -1958,7 +1958,9 @@ int wgrad2_splits(const UnetConvDesc* d, const Phases& ph, int groups) {
 }
 }  // namespace
 
-extern "C" size_t unet_conv1d_wgrad_workspace_bytes(const UnetConvDesc* d) {
+namespace {
+// wide: count the 256 x 256-tile kernel's slabs too (it is skipped at call time when the workspace cannot hold them)
+size_t wgrad_ws_bytes(const UnetConvDesc* d, bool wide) {
   Phases ph;
   if (!d || analyse(d, &ph) || d->n_taps <= 0) return 0;
   // the kernel (v1 / v2) is chosen at call time from pointer alignment: size for the larger slab count
@@ -1968,10 +1970,13 @@ extern "C" size_t unet_conv1d_wgrad_workspace_bytes(const UnetConvDesc* d) {
     wgrad_groups(d, &g);
     const int s2 = wgrad2_splits(d, ph, g.n);
     if (s2 > s) s = s2;
-    if (wgrad3_ok(d) && wgrad3_splits(d) > s) s = wgrad3_splits(d);
+    if (wide && wgrad3_ok(d) && wgrad3_splits(d) > s) s = wgrad3_splits(d);
   }
   return (size_t)s * d->n_taps * d->c_out * (d->c1 + d->c2) * sizeof(float);
 }
+}  // namespace
+
+extern "C" size_t unet_conv1d_wgrad_workspace_bytes(const UnetConvDesc* d) { return wgrad_ws_bytes(d, true); }
 
 namespace {
 int wgrad_impl(const UnetConvDesc* d, const void* x1, const void* x2, const void* dy, float* dw, void* workspace,
@@ -2018,7 +2023,8 @@ extern "C" size_t unet_conv1d_wgrad_noalloc_max_bytes(void) { return (size_t)UNE
 extern "C" int unet_conv1d_wgrad_noalloc(const UnetConvDesc* d, const void* x1, const void* x2, const void* dy,
                                          float* dw, void* stream) {
   UNET_REQUIRE(d && x1 && dy && dw, "conv_wgrad_noalloc: null pointer");
-  const size_t need = unet_conv1d_wgrad_workspace_bytes(d);
+  size_t need = wgrad_ws_bytes(d, true);
+  if (need > (size_t)UNET_NOALLOC_SCRATCH_BYTES) need = wgrad_ws_bytes(d, false);   // without the wide kernel's slabs
   UNET_REQUIRE(need > 0, "conv_wgrad_noalloc: bad descriptor");
   UNET_REQUIRE(need <= (size_t)UNET_NOALLOC_SCRATCH_BYTES,
                "conv_wgrad_noalloc: the split-K slabs of this conv need %zu bytes, the built-in scratch holds %zu; "
@@ -2041,11 +2047,12 @@ int wgrad_impl(const UnetConvDesc* d, const void* x1, const void* x2, const void
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long count = (long long)d->n_taps * d->c_out * (d->c1 + d->c2);
   g_last_variant = UNET_VARIANT_WGRAD_GENERIC;
-  if (wgrad2_ok(d, x1, x2, dy) && wgrad3_ok(d)) {
+  // (a workspace too small for the wide kernel's slabs -- the allocation-free entry point's fixed scratch -- takes the
+  // paired kernel below, which needs fewer)
+  if (wgrad2_ok(d, x1, x2, dy) && wgrad3_ok(d) && workspace &&
+      ws_bytes >= (size_t)wgrad3_splits(d) * count * sizeof(float)) {
     g_last_variant = UNET_VARIANT_WGRAD_WIDE;
     const int splits = wgrad3_splits(d);
-    const size_t need = (size_t)splits * count * sizeof(float);
-    UNET_REQUIRE(workspace && ws_bytes >= need, "conv_wgrad: workspace %zu bytes < %zu needed", ws_bytes, need);
     Wg3K k;
     k.x = static_cast<const char*>(x1); k.dy = static_cast<const char*>(dy); k.slab = static_cast<float*>(workspace);
     k.x_ns = d->x1_ns; k.dy_ns = d->y_ns; k.x_ld = d->x1_ld; k.dy_ld = d->y_ld;
