@@ -33,6 +33,10 @@ initialised: fold-parallel LOSO runs a different (fold, seed) job on every rank 
 job must not broadcast weights, average gradients or share early-stop decisions with the other ranks."""
 
 
+def _pad4(n: int) -> int:
+    return (n + 3) & ~3
+
+
 def group_active(process_group=None) -> bool:
     return process_group is not NO_GROUP and dist.is_available() and dist.is_initialized()
 
@@ -84,11 +88,13 @@ class BucketedGradAllReduce:
         if n_tail:
             self._groups.append(list(reversed(self.params[:n_tail])))
         for b, group in enumerate(self._groups):
-            flat = torch.zeros(sum(p.numel() for p in group), dtype=torch.float32, device=group[0].device)
+            # every view starts on a 16-byte boundary (the padding stays zero on every rank): the optimizer's float4
+            # path (optim.ClipAdamW) and RCCL both see aligned tensors
+            flat = torch.zeros(sum(_pad4(p.numel()) for p in group), dtype=torch.float32, device=group[0].device)
             views, off = [], 0
             for p in group:
                 views.append(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
+                off += _pad4(p.numel())
                 self._bucket_of[p] = b
             self.buckets.append(flat)
             self._views.append(views)

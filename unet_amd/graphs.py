@@ -28,7 +28,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
-from .dp import BucketedGradAllReduce, _has_avg, group_size
+from .dp import _pad4, BucketedGradAllReduce, _has_avg, group_size
 
 
 def _capture_mode() -> str:
@@ -161,11 +161,11 @@ class GraphedTrainStep:
             groups.append(cur)
         view_of = {}
         for grp in groups:
-            flat = torch.zeros(sum(p.numel() for p in grp), dtype=torch.float32, device=grp[0].device)
+            flat = torch.zeros(sum(_pad4(p.numel()) for p in grp), dtype=torch.float32, device=grp[0].device)
             off = 0
             for p in grp:
-                view_of[p] = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
+                view_of[p] = flat[off:off + p.numel()].view_as(p)     # 16-byte aligned views, zero padding
+                off += _pad4(p.numel())
             self._flat.append(flat)
         self._views = [view_of[p] for p in self.params]
 
