@@ -257,3 +257,81 @@ def test_fold_parallel_loso_with_real_trainers_equals_serial(tmp_path):
         assert res[rank][1] == serial["summary"], rank
     jobs = loso_jobs(["a", "b", "c"], 7, 1, None)
     assert sorted(os.listdir(tmp_path)) == sorted(f"f{j.fold_idx}s{j.seed_idx}.pt" for j in jobs)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sliding-window inference: ranks that SHARE a recording (default group) and ranks that do not (dp.NO_GROUP)
+# ---------------------------------------------------------------------------------------------------------------
+def _overlap_average(preds, first, total, stride, n_samples, out):
+    """numpy restatement of the overlap accumulation (phase_five/sliding_window.py:238-251), raw sums only"""
+    for i, p in enumerate(preds):
+        s = (first + i) * stride
+        out[:, s:s + p.shape[1]] += p
+
+
+def _stub_inference(signal, scale, window_size, stride, process_group):
+    """The host logic of infer.continuous_inference (plan_windows -> per-rank window range -> raw sums ->
+    merge_seams -> division by the geometric count) around a stub model ``x -> scale * x + 1`` on CPU tensors."""
+    import numpy as np
+    from unet_amd.infer import merge_seams, plan_windows
+    n_ch, n_samples = signal.shape
+    total, shard, world = plan_windows(n_samples, window_size, stride, process_group)
+    out = np.zeros((n_ch, n_samples), dtype=np.float64)
+    preds = [scale * signal[:, (shard.first_window + i) * stride:(shard.first_window + i) * stride + window_size] + 1.0
+             for i in range(shard.n_windows)]
+    _overlap_average(preds, shard.first_window, total, stride, n_samples, out)
+    t = torch.from_numpy(out)
+    merge_seams(t, process_group)
+    counts = np.zeros(n_samples)
+    for i in range(total):
+        counts[i * stride:i * stride + window_size] += 1
+    return t.numpy() / np.maximum(counts, 1), shard, world
+
+
+def _infer_worker(rank, world, port, q):
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unet_amd.dp import NO_GROUP
+    rng = np.random.default_rng(0)
+    shared = rng.standard_normal((3, 1037))
+    own = np.random.default_rng(10 + rank).standard_normal((3, 900 + 50 * rank))     # this rank's fold recording
+    # 1. fold-parallel: every rank runs ITS fold's model over ITS recording, lengths differ; nothing may be exchanged
+    solo, shard, w = _stub_inference(own, 2.0 + rank, 100, 50, NO_GROUP)
+    assert w == 1 and shard.first_window == 0
+    # 2. the ranks share one recording
+    both, shard2, w2 = _stub_inference(shared, 3.0, 100, 30, None)
+    q.put((rank, solo, both, (shard2.first_window, shard2.n_windows), w2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sliding_window_inference_group_handling_two_ranks():
+    """infer.plan_windows / merge_seams: under dp.NO_GROUP a rank processes its whole recording alone (different
+    recordings and window counts per rank: a collective would hang or mix folds); with the default group two ranks
+    split one recording's windows and one all-reduce of the raw sums gives the serial result on both."""
+    import numpy as np
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_infer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, solo, both, shard, w2 = q.get(timeout=120)
+        res[rank] = (solo, both, shard, w2)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shared = np.random.default_rng(0).standard_normal((3, 1037))
+    serial_shared, _, w = _stub_inference(shared, 3.0, 100, 30, None)          # no process group here: one rank
+    assert w == 1
+    for rank in range(world):
+        own = np.random.default_rng(10 + rank).standard_normal((3, 900 + 50 * rank))
+        serial_own, _, _ = _stub_inference(own, 2.0 + rank, 100, 50, None)
+        assert np.array_equal(res[rank][0], serial_own), rank
+        assert np.allclose(res[rank][1], serial_shared, rtol=0, atol=1e-12), rank
+        assert res[rank][3] == 2
+    total = (1037 - 100) // 30 + 1
+    assert res[0][2][0] == 0 and res[0][2][0] + res[0][2][1] == res[1][2][0] and res[1][2][0] + res[1][2][1] == total

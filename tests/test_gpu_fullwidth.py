@@ -20,7 +20,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from oracle.make_golden_fullwidth import CASES, block_names, build_case, strided, sums
+from oracle.make_golden_fullwidth import CASES, block_names, build_case, scattered, strided, sums
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -36,7 +36,11 @@ def _record(name):
 
 
 def _slice_rel(t, z, key):
-    return rel(strided(t.float().cpu()), torch.from_numpy(z[key + "/slice"]))
+    """Worse of the two samples of the record: a prime-strided slice (all taps / tile residues / tile edges) and a
+    seeded random index set."""
+    t = t.detach().float()
+    return max(rel(strided(t), torch.from_numpy(z[key + "/slice"])),
+               rel(scattered(t), torch.from_numpy(z[key + "/rslice"])))
 
 
 def _sum_err(t, z, key):
@@ -134,9 +138,14 @@ def test_fullwidth_bf16_close_to_reference(name):
         if k not in norms or norms[k] < floor:
             continue
         e = _slice_rel(p.grad, z, f"lingrad/{k}")
-        tol = 3e-1 if p.numel() <= 4 else 1e-1       # scale_weights: differences of large sums (tests/test_gpu_model.py)
+        tol = 1e-1
+        if p.numel() <= 4:
+            # scale_weights: 4 numbers, each a difference of sums over ~10^7 products.  DERIVED bar: the record holds
+            # how far the reference's own fp32 evaluation moves this tensor when only its inputs (weights, window)
+            # are rounded to bf16 -- a bf16 evaluation also rounds ~10 layers of activations on top of that
+            tol = min(0.5, max(1e-1, 4.0 * float(z[f"bf16in/{k}"])))
         if e > tol:
-            bad.append((k, e))
+            bad.append((k, e, tol))
     assert not bad, bad
     model.eval()
     with torch.no_grad():
@@ -246,6 +255,22 @@ def test_merged_dilated_conv_at_config_b_layer_shapes(shape):
                                     stride=stride, padding=3 * d, dilation=d)
     dy = torch.randn(yr.shape, device="cuda").bfloat16()
     yr.backward(dy.float())
+    # scale_weights: 4 numbers, each w_i * (g_i - <w, g>) with g_n = <dy, conv_n(x)> a sum of ~10^10 signed products.
+    # Its bar is DERIVED from the fp32 reference's own summation noise: the same gradient from the same fp32 torch ops
+    # evaluated window by window (another summation order) differs from the batched one by `noise`; two correct fp32
+    # evaluations cannot be expected to agree better than a few times that.
+    sw = params["scale_weights"].detach().clone().requires_grad_(True)
+    for i0 in range(n):
+        wsm2 = torch.softmax(sw, 0)
+        yi = 0
+        for i, d in enumerate((1, 4, 16, 32)):
+            yi = yi + wsm2[i] * F.conv1d(x[i0:i0 + 1].float(), params[f"branches.{i}.conv.weight"].detach(),
+                                         params[f"branches.{i}.conv.bias"].detach(), stride=stride, padding=3 * d,
+                                         dilation=d)
+        (yi * dy[i0:i0 + 1].float()).sum().backward()
+    noise = rel(sw.grad, params["scale_weights"].grad)
+    small_bar = max(1.5e-2, 8.0 * noise)
+    assert small_bar < 0.25, noise             # the derivation itself must stay meaningful
     xd = x.permute(0, 2, 1).contiguous().requires_grad_(True)
     y = blk.forward_nlc(xd)
     assert int(_lib.load().unet_conv1d_last_variant()) == FWD_TILED
@@ -253,8 +278,7 @@ def test_merged_dilated_conv_at_config_b_layer_shapes(shape):
     assert rel(y.permute(0, 2, 1), yr) < 1.5e-2
     assert rel(xd.grad.permute(0, 2, 1), xr.grad) < 1.5e-2
     for k, p in blk.named_parameters():
-        # scale_weights: 4 numbers, each the difference of sums over 10^7 products (see tests/test_gpu_model.py)
-        assert rel(p.grad, params[k].grad) < (5e-2 if p.numel() <= 4 else 1.5e-2), k
+        assert rel(p.grad, params[k].grad) < (small_bar if p.numel() <= 4 else 1.5e-2), (k, noise)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -273,28 +297,38 @@ def test_n64_eval_batch_split_invariance_and_gradient_linearity():
         out64 = model(x, id64)
         out2 = model(x[:2].contiguous(), id64[:2])
         out8 = model(x[8:16].contiguous(), id64[8:16])
-    # the same windows inside a 64-window batch and alone.  Not bit-exact: the [N, 128] -> [N, C] Linear layers of
-    # SE / FiLM run on library GEMMs whose algorithm (summation order) depends on N, and an fp32 ulp there flips bf16
-    # roundings downstream; the bar is 1/15 of the bf16 output bar
-    assert rel(out64[:2], out2) < 2e-3
-    assert rel(out64[8:16], out8) < 2e-3
+    # the same windows inside a 64-window batch and alone: BIT-EXACT.  No kernel on the eval path lets the batch size
+    # into a window's summation order (tile choice and split counts depend on channels / length only; the [N, emb]
+    # linears of SE / FiLM run on csrc/small.hip with a fixed 64-window tile and split-K of 128).  Round 2 saw 1.7e-4
+    # here while those linears were library GEMMs that picked their algorithm by N; scripts/diag_split.py prints the
+    # per-block comparison (all blocks equal for sub-batches [0:1], [0:2], [8:16], [32:64] of a 64-window batch).
+    assert torch.equal(out64[:2], out2)
+    assert torch.equal(out64[8:16], out8)
     assert _slice_rel(out2, z, "pred_eval") < 3e-2   # and the two golden windows still match the reference
     # gradient linearity in the batch: one 64-window backward == eight accumulated 8-window backwards
     G = torch.randn(out64.shape, generator=torch.Generator().manual_seed(6)).cuda() / out64[0].numel()
     model.zero_grad(set_to_none=True)
     (model(x, id64) * G).sum().backward()
     g64 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
-    model.zero_grad(set_to_none=True)
+    chunks = []
     for i in range(0, 64, 8):
+        model.zero_grad(set_to_none=True)
         (model(x[i:i + 8].contiguous(), id64[i:i + 8]) * G[i:i + 8]).sum().backward()
+        chunks.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
     floor = 1e-5 * max(v.norm().item() for v in g64.values())
     bad = []
-    for k, p in model.named_parameters():
-        if k not in g64 or g64[k].norm().item() < floor:
+    for k, g_all in g64.items():
+        if g_all.norm().item() < floor:
             continue
-        e = rel(p.grad, g64[k])
-        if e > (5e-2 if p.numel() <= 4 else 1e-2):   # same bf16 products, different fp32 summation order
-            bad.append((k, e))
+        acc = sum(c[k].double() for c in chunks)
+        err = (acc - g_all.double()).norm().item()
+        # same bf16 products, different fp32 summation order: the difference scales with the magnitude of the ADDENDS.
+        # For the large tensors that is the gradient's own norm (bar 1e-2 relative).  A <= 4-element tensor
+        # (scale_weights) is a small difference of large sums, so its bar is stated against what was added up --
+        # the norms of the eight partial gradients -- not against the cancelled total.
+        scale = g_all.norm().item() if g_all.numel() > 4 else sum(c[k].norm().item() for c in chunks)
+        if err > 1e-2 * scale:
+            bad.append((k, err / scale))
     assert not bad, bad
 
 

@@ -31,6 +31,15 @@ def _check_bf16_grads(mine, ref, tol, small_bar=None):
         bar = tol
         if v.numel() <= 4:
             bar = small_bar[k] if small_bar is not None else 3 * tol
+        if bar is None:
+            # not resolvable in bf16 (see _bf16_sensitivity): rounding the INPUTS alone moves this gradient by more
+            # than 1/8 of itself, so no relative bar below 0.5 can be derived for a bf16 evaluation.  What is still
+            # required: the right direction and the right order of magnitude.
+            cos = float((mine[k].double().cpu() * v.double().cpu()).sum()) / max(
+                float(mine[k].double().norm()) * float(v.double().norm()), 1e-300)
+            if not (cos > 0.5 and r < 1.0):
+                bad.append((k, r, "direction/magnitude only", cos))
+            continue
         if r > bar:
             bad.append((k, r, bar))
     assert not bad, bad
@@ -52,10 +61,11 @@ def _bf16_sensitivity(O, g, G, ref_grads, tol):
     bars = {}
     for k, v in ref_grads.items():
         if v.numel() <= 4 and leaves[k].grad is not None:
-            # capped at 1: a gradient that input rounding alone moves by > 25 % (the attention key bias, whose true
-            # gradient is zero by the softmax's shift invariance; gamma of the base-8 fixture: measured 26 %, which
-            # is where round 1's observed 0.29 comes from) is only required to stay within its own magnitude
-            bars[k] = min(1.0, max(tol, 4 * rel(leaves[k].grad, v)))
+            # a gradient that input rounding alone moves by > 12.5 % (gamma of the base-8 fixture: measured 26 %,
+            # which is where round 1's observed 0.29 comes from) gets NO relative bar (None): _check_bf16_grads then
+            # only requires direction and order of magnitude, and says so, instead of a bar of 1.0 that tests nothing
+            dev = 4 * rel(leaves[k].grad, v)
+            bars[k] = None if dev > 0.5 else max(tol, dev)
     return bars
 
 
@@ -245,3 +255,48 @@ def test_inference_reuses_packed_weights_until_a_parameter_changes():
         y3 = model(ob, **_kw(g))
     assert rel(y3.detach(), y2) < 5e-3
     ops.clear_pack_cache()
+
+
+def test_packed_weight_cache_does_not_outlive_its_model():
+    """Checkpoint after checkpoint evaluated in one inference process (LOSO fold models): a freed model's blocks come
+    back from the caching allocator at the same addresses with the same version counts, so the cache must key on the
+    Parameter objects themselves (weak references).  Models are built, loaded and dropped one after the other with
+    different weights; each must answer with its OWN weights."""
+    import gc
+    import unet_amd
+    from unet_amd import ops
+    g = Golden("B2_modern_concat")
+    ob = g.t("ob").cuda()
+    sd0 = g.state_dict()
+    ops.clear_pack_cache()
+
+    def run(scale, keep_cache=True):
+        sd = {k: (v * scale if (v.is_floating_point() and v.dim() == 3) else v) for k, v in sd0.items()}
+        sd["outc.weight"] = torch.full_like(sd0["outc.weight"], 0.05 * scale)     # outc is zero-initialised
+        model = unet_amd.CondUNet1D(**g.cfg).cuda()
+        model.set_compute_dtype(torch.bfloat16)
+        if keep_cache:
+            # fill the tensors behind the cache's back (no version bump, no load_state_dict hook): the weak
+            # references alone must tell this model's parameters from the previous model's
+            n_before = len(ops._PACK_CACHE)
+            for k, v in model.state_dict(keep_vars=True).items():
+                v.data.copy_(sd[k])
+            assert len(ops._PACK_CACHE) == n_before
+        else:
+            model.load_state_dict(sd, strict=True)
+            ops.clear_pack_cache()
+        model.eval()
+        with torch.no_grad():
+            y = model(ob, **_kw(g)).clone()
+        ptrs = sorted(p.data_ptr() for p in model.parameters())
+        del model
+        gc.collect()
+        return y, ptrs
+
+    want = [run(s, keep_cache=False)[0] for s in (1.0, 1.5, 0.5)]          # each with a cold cache
+    ops.clear_pack_cache()
+    got, ptrs = zip(*[run(s) for s in (1.0, 1.5, 0.5)])                     # cache left alone between models
+    assert rel(want[1], want[0]) > 2e-3 and rel(want[2], want[0]) > 2e-3    # the weights do matter
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert not ops._PACK_CACHE                                              # entries died with their parameters

@@ -131,3 +131,44 @@ def test_more_tensors_than_one_table_and_graph_capture():
     for p, q in zip(pa, pb):
         torch.testing.assert_close(opt.state[q]["exp_avg"], ref.state[p]["exp_avg"], rtol=3e-5, atol=1e-7)
     assert float(opt.state[pb[0]]["step"]) == 4.0        # one eager step + three replays (the capture itself runs nothing)
+
+
+def test_loading_a_torch_adamw_state_keeps_the_clip_and_the_device_lr():
+    """torch's Optimizer.load_state_dict replaces every param_group by the saved one: a reference checkpoint
+    (torch.optim.AdamW: no ``max_grad_norm`` key, float ``lr``) must neither switch the clip off nor replace the
+    device-scalar learning rate a captured step reads through its pointer."""
+    import copy
+    from unet_amd.optim import ClipAdamW
+    dev = "cuda"
+    shapes = SHAPES[:6]
+    pa, pb = _params(6, shapes, dev), _params(6, shapes, dev)
+    ref = torch.optim.AdamW(pa, lr=3e-4, betas=BETAS, weight_decay=0.0)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for p in pa:
+        p.grad = torch.randn(p.shape, generator=g).to(dev)
+    ref.step()
+    with torch.no_grad():
+        for p, q in zip(pa, pb):
+            q.copy_(p)
+    lr = torch.tensor(1e-3, device=dev)
+    opt = ClipAdamW(pb, lr=lr, betas=BETAS, weight_decay=0.0, max_grad_norm=5.0)
+    opt.load_state_dict(copy.deepcopy(ref.state_dict()))
+    group = opt.param_groups[0]
+    assert group["max_grad_norm"] == 5.0
+    assert group["lr"] is lr and abs(float(lr) - 3e-4) < 1e-10          # same tensor, loaded value
+    grads = [torch.randn(p.shape, generator=g).to(dev) * 50.0 for p in pa]    # norm far above 5
+    for p, q, gr in zip(pa, pb, grads):
+        p.grad = gr.clone()
+        q.grad = gr.clone()
+    total = torch.nn.utils.clip_grad_norm_(pa, 5.0)
+    assert float(total) > 50.0
+    ref.step()
+    opt.step()
+    assert abs(float(opt.total_norm()) - float(total)) <= 2e-6 * float(total)
+    for p, q in zip(pa, pb):                   # the step taken is the CLIPPED one
+        torch.testing.assert_close(opt.state[q]["exp_avg"], ref.state[p]["exp_avg"], rtol=2e-5, atol=1e-7)
+        assert float((p - q).detach().abs().max()) <= 3e-4 * 1e-4 + 1e-6 * float(p.detach().abs().max())
+    # a group-level max_grad_norm saved by ClipAdamW itself wins over the constructor's
+    opt2 = ClipAdamW(_params(6, shapes, dev), lr=1e-3, betas=BETAS, weight_decay=0.0, max_grad_norm=1.0)
+    opt2.load_state_dict(copy.deepcopy(opt.state_dict()))
+    assert opt2.param_groups[0]["max_grad_norm"] == 5.0

@@ -16,7 +16,7 @@ Design (MI355X-first, not DDP's reducer re-typed):
   * BatchNorm buffers are never synchronised (per-rank statistics, as in the reference:
     ``broadcast_buffers=False``); rank 0's buffers are what a checkpoint holds;
   * xGMI is point-to-point (7 links per GPU), so fewer, larger buckets are preferred: default
-    64 MiB (the 168 MB of config-B gradients travel as 3 messages);
+    64 MiB (the 168 MB of config-B gradients travel as 3 messages plus a <= 4 MiB tail, see ``tail_bytes``);
   * with one process there is nothing to exchange and the class is a no-op around autograd.
 """
 from __future__ import annotations
@@ -66,6 +66,9 @@ class BucketedGradAllReduce:
         self._bucket_of = {}
         self._handles = []
         self._hooks = []
+        for p in self.params:                   # all of them, the tail bucket's included
+            if p.dtype != torch.float32:
+                raise TypeError("gradient buckets are fp32 (master weights are fp32, as in the reference)")
         n_tail, tail_elems = 0, 0
         for p in self.params:
             if (tail_elems + p.numel()) * 4 > tail_bytes:
@@ -76,8 +79,6 @@ class BucketedGradAllReduce:
             n_tail = 0                          # everything fits one small bucket: no separate tail
         cur, cur_elems = [], 0
         for p in reversed(self.params[n_tail:]):
-            if p.dtype != torch.float32:
-                raise TypeError("gradient buckets are fp32 (master weights are fp32, as in the reference)")
             if cur and (cur_elems + p.numel()) * 4 > bucket_bytes:
                 self._groups.append(cur)
                 cur, cur_elems = [], 0

@@ -22,6 +22,7 @@ import torch.distributed as dist
 
 from . import _lib
 from ._lib import check
+from .dp import group_rank, group_size
 from .ops import _dt, _p, _stream
 from .windows import n_windows_inference, shard_windows
 
@@ -43,13 +44,35 @@ def overlap_add(pred: torch.Tensor, first_window: int, total_windows: int, strid
                                        int(finalize), _MODES[mode], _stream()), "unet_overlap_add")
 
 
+def plan_windows(n_samples: int, window_size: int, stride: int, process_group=None):
+    """Host side of the sharding: (total windows of the recording, this rank's contiguous share of them, number of
+    ranks sharing the recording).  ``dp.NO_GROUP`` (or no process group at all) = one rank owns every window."""
+    total = n_windows_inference(n_samples, window_size, stride)
+    world = group_size(process_group)              # 1 without torch.distributed and under dp.NO_GROUP
+    rank = group_rank(process_group)
+    return total, shard_windows(total, world, window_size, stride)[rank], world
+
+
+def merge_seams(out: torch.Tensor, process_group=None):
+    """One all-reduce (SUM) of the raw overlap sums across the ranks that share the recording; nothing to do for a
+    rank that owns it alone."""
+    if group_size(process_group) > 1:
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=process_group)
+    return out
+
+
 @torch.no_grad()
 def continuous_inference(model: torch.nn.Module, signal, window_size: int, stride: int, device="cuda",
                          overlap_mode: str = "average", batch_windows: int = 64, process_group=None,
                          return_tensor: bool = False, model_kwargs: Optional[dict] = None):
     """Drop-in for phase_five/sliding_window.py:256-278: ``signal`` is ``[n_channels, n_samples]``
     (numpy or tensor); returns the continuous prediction ``[n_out_channels, n_samples]`` (numpy float32
-    unless ``return_tensor``).  ``model(x)`` is called on ``[B, C, W]`` batches in eval mode."""
+    unless ``return_tensor``).  ``model(x)`` is called on ``[B, C, W]`` batches in eval mode.
+
+    ``process_group``: the ranks that SHARE this recording (default: all of them, each takes a contiguous range of
+    windows and the seams are merged by one all-reduce).  ``dp.NO_GROUP`` = this rank alone processes the whole
+    recording although ``torch.distributed`` is up: inference inside a fold-parallel LOSO job, where the other ranks
+    run other folds' models and must not be met in a collective."""
     if overlap_mode not in _MODES:
         raise ValueError(f"Unknown overlap_mode: {overlap_mode}. Available: average, last, first")
     dev = torch.device(device)
@@ -62,10 +85,7 @@ def continuous_inference(model: torch.nn.Module, signal, window_size: int, strid
         sig = sig.float()
     sig = sig.to(dev, non_blocking=True).contiguous()          # ONE upload of the whole recording
     n_ch, n_samples = sig.shape
-    total = n_windows_inference(n_samples, window_size, stride)
-    world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-    rank = dist.get_rank(process_group) if world > 1 else 0
-    shard = shard_windows(total, world, window_size, stride)[rank]
+    total, shard, world = plan_windows(n_samples, window_size, stride, process_group)
     out = None
     windows = sig.unfold(1, window_size, stride).permute(1, 0, 2) if total > 0 else None   # [total, C, W] view
     kw = model_kwargs or {}
@@ -83,8 +103,7 @@ def continuous_inference(model: torch.nn.Module, signal, window_size: int, strid
     if out is None:
         n_out = getattr(model, "out_channels", n_ch)
         out = torch.zeros((n_out, n_samples), dtype=torch.float32, device=dev)
-    if world > 1:
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=process_group)
+    merge_seams(out, process_group)
     if overlap_mode == "average" and total > 0:
         overlap_add(None, 0, total, stride, out, accumulate=True, finalize=True, window_size=window_size)
     return out if return_tensor else out.cpu().numpy()

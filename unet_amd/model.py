@@ -858,6 +858,14 @@ class CondUNet1D(nn.Module):
             ops.clear_pack_cache()
         return super().train(mode)
 
+    def load_state_dict(self, *args, **kwargs):
+        ops.clear_pack_cache()              # copy_ bumps the versions anyway; loading is rare, so be unconditional
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        ops.clear_pack_cache()              # .to() / .cuda() / .half(): new storages behind the same Parameter objects
+        return super()._apply(fn, *args, **kwargs)
+
     def set_compute_dtype(self, dtype: Optional[torch.dtype]):
         """bf16 or fp32 kernels regardless of the input dtype (None = follow the input)."""
         if dtype not in (None, torch.float32, torch.bfloat16):

@@ -577,14 +577,22 @@ def _cacheable(params) -> bool:
 
 def packed_for_inference(tag, params: Sequence[Tensor], dtype: int, build):
     """``build()`` -> tuple of tensors (packed weights, fp32 bias, ...) derived from ``params``; cached per
-    (tag, dtype, parameter identities) while every parameter's ``_version`` is unchanged."""
-    key = (tag, dtype) + tuple(p.data_ptr() for p in params)
-    versions = tuple(p._version for p in params)
+    (tag, dtype, parameter identities) while every parameter's ``_version`` is unchanged.  Identity means the
+    Parameter OBJECT: the entry holds weak references and a hit requires ``ref() is p`` for every parameter, and the
+    entry is dropped when any of them dies -- a process that evaluates checkpoint after checkpoint gets freed blocks
+    back at the same addresses with the same version counts, so neither ``data_ptr()`` nor ``id()`` alone names a
+    tensor."""
+    key = (tag, dtype) + tuple(id(p) for p in params)
+    versions = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
     hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] == versions:
+    if hit is not None and hit[0] == versions and all(r() is p for r, p in zip(hit[2], params)):
         return hit[1]
     val = build()
-    _PACK_CACHE[key] = (versions, val)
+
+    def evict(_ref, key=key):
+        _PACK_CACHE.pop(key, None)
+
+    _PACK_CACHE[key] = (versions, val, tuple(weakref.ref(p, evict) for p in params))
     return val
 
 

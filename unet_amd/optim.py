@@ -109,7 +109,18 @@ class ClipAdamW(torch.optim.Optimizer):
         return g
 
     def load_state_dict(self, state_dict):
+        """As ``torch.optim.Optimizer.load_state_dict``, except for two things torch's version loses: it replaces
+        every param_group by the saved one, so a ``torch.optim.AdamW`` checkpoint of the reference (no
+        ``max_grad_norm`` key) would silently switch the clip off, and a device-scalar ``lr`` (graph-captured steps
+        read it through its pointer) would become a float no captured step sees."""
+        before = [(g.get("max_grad_norm"), g.get("lr")) for g in self.param_groups]
         super().load_state_dict(state_dict)
+        for group, (max_norm, lr) in zip(self.param_groups, before):
+            if "max_grad_norm" not in group:
+                group["max_grad_norm"] = max_norm
+            if isinstance(lr, torch.Tensor):
+                lr.fill_(float(group["lr"]))      # keep the tensor (and its address), take the loaded value
+                group["lr"] = lr
         self._groups = {}                  # the loaded moments are copied into fresh flat buffers at the next step
 
     def total_norm(self, group_index: int = 0) -> torch.Tensor:
