@@ -82,11 +82,11 @@ def parse():
     ap.add_argument("--attention", default="none", choices=["none", "cross_freq_v2"],
                     help="cross_freq_v2: the phase-four / phase-five bottleneck attention (band-pair flash kernels); the "
                          "headline config B has none")
-    ap.add_argument("--graph", action="store_true", help="replay the captured HIP graph also for N > 1 (all-reduce runs "
-                    "between the two graphs, not overlapped); default for N > 1 is the eager hook-driven path")
-    ap.add_argument("--graph-overlap", action="store_true", help="N > 1: ONE captured graph with the bucket all-reduces "
-                    "inside it, forked off the backward stream (graphs.GraphedTrainStep(overlap=True)); falls back to the "
-                    "eager hook-driven path if the capture is refused")
+    ap.add_argument("--graph", action="store_true", help="N > 1: two captured graphs with the all-reduce between them "
+                    "(no overlap of communication with backward)")
+    ap.add_argument("--graph-overlap", action="store_true", help="N > 1 (the default there): ONE captured graph with the "
+                    "bucket all-reduces inside it, forked off the backward stream (graphs.GraphedTrainStep(overlap=True)); "
+                    "if any rank's capture is refused, every rank falls back to the eager hook-driven path")
     ap.add_argument("--dp-selftest", action="store_true", help="N = 1 only: run the N > 1 code path (eager launches, bucket "
                     "hooks, one RCCL all-reduce per bucket) through a one-rank process group with the collectives forced on; "
                     "measures what the data-parallel machinery costs beside the step, not the xGMI transport")
@@ -145,11 +145,11 @@ def cpu_baseline(n_windows: int, cfg, gflop_fwd: float):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # N > 1: kernels are launched one by one so that each gradient bucket's RCCL all-reduce starts from its autograd
-    # hook and overlaps the rest of backward (the host enqueues a step in ~18 ms, the GPU needs ~28 ms, so the
-    # launches stay ahead); the captured graph has no such overlap (fwd+bwd graph -> all-reduce -> update graph).
-    if world > 1 and not (args.graph or args.graph_overlap):
-        args.eager = True
+    # N > 1 default: the whole step incl. the bucket all-reduces as ONE captured graph (each bucket's collective is
+    # forked off the captured backward when its last gradient lands, so it overlaps the rest of backward); --eager is
+    # the same protocol with kernels launched one by one (hooks), and the fallback if a capture is refused.
+    if world > 1 and not (args.graph or args.eager) and args.conditioning == "odor_onehot":
+        args.graph_overlap = True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -230,9 +230,16 @@ def main():
             traceback.print_exc()
             print(f"[bench] HIP-graph capture failed ({type(e).__name__}); running eagerly", file=sys.stderr)
             graphed = None
+        if world > 1:           # one rank on the eager path, the others replaying: keep them on the same protocol
+            ok = torch.tensor([1.0 if graphed is not None else 0.0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 0.0:
+                graphed = None
+        if graphed is None:
+            mode = "eager"
             opt = make_optimizer(False)
     if graphed is None:
-        reducer = BucketedGradAllReduce(model.parameters(), force=args.dp_selftest)
+        reducer = BucketedGradAllReduce(model, force=args.dp_selftest)
 
     def step():
         if graphed is not None:

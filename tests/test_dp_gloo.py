@@ -111,7 +111,7 @@ def _loso_worker(rank, world, port, q):
         ran.append((job.fold_idx, job.seed_idx))
         return {"val_r2": 0.1 * job.fold_idx + 0.01 * job.seed_idx, "val_corr": 0.5, "val_loss": float(job.run_seed)}
 
-    out = run_loso(["a", "b", "c"], run_fold, seed=42, n_seeds=2)
+    out = run_loso(["a", "b", "c"], run_fold, seed=42, n_seeds=2, schedule="static")
     q.put((rank, ran, out["summary"], {k: v["val_r2"] for k, v in out["per_fold"].items()}))
     dist.barrier()
     dist.destroy_process_group()
@@ -140,6 +140,62 @@ def test_fold_parallel_loso_two_ranks():
     assert abs(res[0][2][1] - 0.105) < 1e-12
     assert abs(res[0][1]["mean_r2"] - 0.105) < 1e-12
     assert abs(res[0][1]["mean_loss"] - (42 + 43 + 44 + 45 + 46 + 47) / 6) < 1e-12
+
+
+def _loso_dynamic_worker(rank, world, port, q):
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unet_amd.trainer import run_loso
+    ran = []
+
+    def run_fold(job):
+        ran.append((job.fold_idx, job.seed_idx))
+        time.sleep(0.6 if rank == 1 else 0.05)            # rank 1's folds "train" 12x longer (no early stop)
+        return {"val_r2": 0.1 * job.fold_idx + 0.01 * job.seed_idx, "val_corr": 0.5, "val_loss": float(job.run_seed)}
+
+    dist.barrier()
+    out = run_loso(["a", "b", "c", "d"], run_fold, seed=42, n_seeds=2)        # 8 jobs, dynamic (default)
+    ran_first, ran[:] = list(ran), []
+    out2 = run_loso(["a", "b"], run_fold, seed=1, n_seeds=1)                    # a second run: fresh counter
+    q.put((rank, ran_first, list(ran), out["summary"], {k: v["val_r2"] for k, v in out["per_fold"].items()},
+           out2["summary"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fold_parallel_loso_dynamic_queue_two_ranks():
+    """Default schedule: jobs are pulled from a shared counter in reference order.  Every (fold, seed) runs exactly
+    once, the rank whose jobs finish early takes more of them, each rank's own sequence stays in reference order, and
+    both ranks aggregate the serial result."""
+    from unet_amd.trainer import run_loso
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_loso_dynamic_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        got = q.get(timeout=120)
+        res[got[0]] = got[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    jobs8 = [(f, s) for f in range(4) for s in range(2)]
+    assert sorted(res[0][0] + res[1][0]) == jobs8                  # first run: each of the 8 jobs exactly once
+    assert sorted(res[0][1] + res[1][1]) == [(0, 0), (1, 0)]       # second run: its own counter
+    for rank in range(world):
+        seq = [jobs8.index(j) for j in res[rank][0]]
+        assert seq == sorted(seq)                                  # reference order within a rank
+    assert len(res[0][0]) > len(res[1][0])        # the fast rank pulled more jobs: no idle GPU behind a static split
+    serial = run_loso(["a", "b", "c", "d"], lambda job: {"val_r2": 0.1 * job.fold_idx + 0.01 * job.seed_idx,
+                                                         "val_corr": 0.5, "val_loss": float(job.run_seed)},
+                      seed=42, n_seeds=2)
+    for rank in range(world):
+        assert res[rank][2] == serial["summary"]
+        assert res[rank][3] == {k: v["val_r2"] for k, v in serial["per_fold"].items()}
+    assert res[0][4] == res[1][4]
 
 
 def _coalesce_worker(rank, world, port, q):
@@ -335,3 +391,117 @@ def test_sliding_window_inference_group_handling_two_ranks():
         assert res[rank][3] == 2
     total = (1037 - 100) // 30 + 1
     assert res[0][2][0] == 0 and res[0][2][0] + res[0][2][1] == res[1][2][0] and res[1][2][0] + res[1][2][1] == total
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# hoisted (late-gradient) parameters travel in the tail bucket
+# ---------------------------------------------------------------------------------------------------------------
+class _HoistedBlock(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(6, 6)
+        self.map = torch.nn.Linear(3, 6)          # the block's embedding map (FiLM k/v/gate in CondUNet1D)
+
+
+class _HoistedModel(torch.nn.Module):
+    """Blocks whose embedding maps are evaluated for ALL blocks in front of the first block, as CondUNet1D.forward
+    does with the FiLM projections: their gradients are produced at the very end of backward although they are
+    registered inside their blocks."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.blocks = torch.nn.ModuleList([_HoistedBlock() for _ in range(4)])
+
+    def late_grad_parameters(self):
+        return [p for b in self.blocks for p in b.map.parameters()]
+
+    def forward(self, x, emb):
+        pre = torch.cat([b.map(emb) for b in self.blocks], dim=1)      # ONE node for every block's map
+        pre = pre.tanh().split(6, dim=1)
+        for b, g in zip(self.blocks, pre):
+            x = torch.tanh(b.lin(x)) * g
+        return x
+
+
+def _hoist_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unet_amd.dp import BucketedGradAllReduce
+    out = {}
+    for tag, use_late in (("late", True), ("plain", False)):
+        model = _HoistedModel()
+        late = model.late_grad_parameters()
+        # a module argument makes the reducer ask the model; an explicit empty list switches the tail placement off
+        red = BucketedGradAllReduce(model, bucket_bytes=400, tail_bytes=0, late_params=None if use_late else [])
+        log = []
+        launch = red._launch
+
+        def spy(b, launch=launch, red=red, log=log, late=late):
+            if not red._launched[b]:
+                log.append((b, sum(p.grad is None for p in late)))      # late gradients still missing at launch time
+            launch(b)
+
+        red._launch = spy
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        for step in range(2):
+            red.zero_grad()
+            torch.manual_seed(7 + 10 * step + rank)
+            model(torch.randn(5, 6), torch.randn(5, 3)).pow(2).sum().backward()
+            red.finish()
+            opt.step()
+        tail = len(red._groups) - 1 if use_late else None
+        out[tag] = (log, tail, [id(p) for p in red._groups[-1]] == [id(p) for p in reversed(late)] if use_late else None,
+                    [p.detach().numpy().copy() for p in model.parameters()])
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hoisted_parameters_ride_the_tail_bucket_and_equal_the_serial_mean_step():
+    """With the FiLM hoist on in a data-parallel job (late_grad_parameters), every block's bucket must launch while
+    backward is still running -- i.e. before the hoisted maps' gradients exist -- and the step must equal the serial
+    step on the mean gradient."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hoist_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, out = q.get(timeout=120)
+        res[rank] = out
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        log, tail, tail_is_late, _ = res[rank]["late"]
+        assert tail_is_late
+        steps = [log[:len(log) // 2], log[len(log) // 2:]]
+        for st in steps:
+            assert [b for b, _ in st] == list(range(tail + 1))          # reverse-registration order, tail last
+            assert all(missing == 8 for b, missing in st[:-1])          # launched before ANY late gradient existed
+            assert st[-1][1] == 0
+        plain = res[rank]["plain"][0]
+        # without the tail placement most buckets hold some block's map and wait for the end of backward
+        half = plain[:len(plain) // 2]
+        assert sum(missing < 8 for _, missing in half[:-1]) >= len(half) // 2
+    # serial reference: mean gradient of the two ranks' batches, same SGD steps
+    model = _HoistedModel()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    for step in range(2):
+        grads = None
+        for rank in range(world):
+            model.zero_grad()
+            torch.manual_seed(7 + 10 * step + rank)
+            model(torch.randn(5, 6), torch.randn(5, 3)).pow(2).sum().backward()
+            g = [p.grad.clone() for p in model.parameters()]
+            grads = g if grads is None else [a + b for a, b in zip(grads, g)]
+        for p, g in zip(model.parameters(), grads):
+            p.grad = g / world
+        opt.step()
+    for tag in ("late", "plain"):
+        for rank in range(world):
+            for p, w in zip(model.parameters(), res[rank][tag][3]):
+                assert torch.allclose(p.detach(), torch.from_numpy(w), atol=1e-6), (tag, rank)

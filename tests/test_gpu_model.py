@@ -300,3 +300,34 @@ def test_packed_weight_cache_does_not_outlive_its_model():
     for a, b in zip(got, want):
         assert torch.equal(a, b)
     assert not ops._PACK_CACHE                                              # entries died with their parameters
+
+
+def test_adaptive_scaling_kernel_statistics_match_the_differentiable_path():
+    """SessionAdaptiveScaling (models.py:2043-2068, on by default in LOSO): with an input that takes no gradient the
+    mean / std come from unet_ncl_moments and gamma / beta ride the output transpose (ops.ToNCLAffineFn); with an input
+    that requires a gradient the statistics stay on torch's differentiable reductions.  Same output, same parameter
+    gradients, and both equal the reference's (golden fixture)."""
+    g = Golden("modern_adaptive_nose")
+    model = _build(g)
+    model.train()
+    ob = g.t("ob").cuda()
+    tgt = g.t("target").cuda()
+    grads = []
+    for need_input_grad in (False, True):
+        model.zero_grad(set_to_none=True)
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.momentum = 0.0                     # keep the buffers: the two passes start from the same state
+        x = ob.clone().requires_grad_(need_input_grad)
+        pred = model(x, **_kw(g))
+        assert rel(pred, g.t("pred")) < 1e-4
+        F.l1_loss(pred[..., g.lo:g.hi], tgt[..., g.lo:g.hi]).backward()
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    scaler_keys = [k for k in grads[0] if k.startswith("adaptive_scaler.")]
+    assert len(scaler_keys) >= 6
+    for k in grads[0]:
+        ref = g.t("grad/" + k)
+        if ref.abs().max().item() < 1e-7:
+            continue
+        assert rel(grads[0][k], ref) < 1e-3, k
+        assert rel(grads[0][k], grads[1][k]) < 1e-5, k

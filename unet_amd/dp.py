@@ -51,11 +51,21 @@ def group_rank(process_group=None) -> int:
 
 class BucketedGradAllReduce:
     def __init__(self, params, bucket_bytes: int = 64 << 20, process_group=None, average: bool = True,
-                 tail_bytes: int = 4 << 20, force: bool = False):
+                 tail_bytes: int = 4 << 20, force: bool = False, late_params=None):
         """``tail_bytes``: the parameters registered first (embedding, ``inc``) produce their gradients last, and the
         bucket that holds them is launched when backward has nothing left to overlap it with; they get a bucket of
-        their own of at most this size, so the exposed message is a few MiB instead of a full bucket."""
+        their own of at most this size, so the exposed message is a few MiB instead of a full bucket.
+        ``late_params``: parameters whose gradients are known to arrive at the very END of backward wherever they are
+        registered (``CondUNet1D.late_grad_parameters()``: the FiLM embedding projections of every block, computed by
+        one hoisted node in front of the first block).  They join the tail bucket; left in their blocks' buckets they
+        would hold every bucket back until backward is over.  ``None``: ask the module (if ``params`` is one) or
+        nobody."""
+        if isinstance(params, torch.nn.Module):
+            if late_params is None and hasattr(params, "late_grad_parameters"):
+                late_params = params.late_grad_parameters()
+            params = params.parameters()
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        late = {id(p) for p in (late_params or ())}
         self.pg = process_group
         self.average = average
         self.world = group_size(process_group)
@@ -77,8 +87,12 @@ class BucketedGradAllReduce:
             tail_elems += p.numel()
         if n_tail == len(self.params):
             n_tail = 0                          # everything fits one small bucket: no separate tail
+        tail = list(self.params[:n_tail]) + [p for p in self.params[n_tail:] if id(p) in late]
+        in_tail = {id(p) for p in tail}
         cur, cur_elems = [], 0
-        for p in reversed(self.params[n_tail:]):
+        for p in reversed(self.params):
+            if id(p) in in_tail:
+                continue
             if cur and (cur_elems + p.numel()) * 4 > bucket_bytes:
                 self._groups.append(cur)
                 cur, cur_elems = [], 0
@@ -86,8 +100,8 @@ class BucketedGradAllReduce:
             cur_elems += p.numel()
         if cur:
             self._groups.append(cur)
-        if n_tail:
-            self._groups.append(list(reversed(self.params[:n_tail])))
+        if tail:
+            self._groups.append(list(reversed(tail)))
         for b, group in enumerate(self._groups):
             # every view starts on a 16-byte boundary (the padding stays zero on every rank): the optimizer's float4
             # path (optim.ClipAdamW) and RCCL both see aligned tensors

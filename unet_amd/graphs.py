@@ -23,6 +23,7 @@ Data parallel, ``overlap=True``: ONE graph that contains the collectives.  The s
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional, Sequence
 
 import torch
@@ -35,7 +36,11 @@ def _capture_mode() -> str:
     """With a process group up, its watchdog thread polls the events of earlier collectives (the warm-up steps', the
     start-up broadcast's) while this thread captures: under the default "global" mode such a call from ANOTHER thread
     invalidates the capture (seen as an intermittent abort inside the captured backward).  "thread_local" confines the
-    capture's restrictions to the capturing thread, which is the only one that issues work here."""
+    capture's restrictions to the capturing thread, which is the only one that issues work here.
+    ``UNET_CAPTURE_MODE`` overrides the choice (scripts/diag_capture_mode.py uses it to show the global-mode failure)."""
+    forced = os.environ.get("UNET_CAPTURE_MODE")
+    if forced in ("global", "thread_local", "relaxed"):
+        return forced
     return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
 
 
@@ -120,7 +125,8 @@ class GraphedTrainStep:
             raise NotImplementedError("overlap=True with extra modules: their per-rank clip precedes their own small "
                                       "all-reduce (train.py:1553-1558); use overlap=False or the eager path")
         model, loss_fn = self.model, self.loss_fn
-        self.reducer = BucketedGradAllReduce(self.model_params, bucket_bytes, self.pg, force=force)
+        late = self.model.late_grad_parameters() if hasattr(self.model, "late_grad_parameters") else None
+        self.reducer = BucketedGradAllReduce(self.model_params, bucket_bytes, self.pg, force=force, late_params=late)
 
         def full_step():
             self.reducer.zero_grad()

@@ -67,7 +67,8 @@ def continuous_inference(model: torch.nn.Module, signal, window_size: int, strid
                          return_tensor: bool = False, model_kwargs: Optional[dict] = None):
     """Drop-in for phase_five/sliding_window.py:256-278: ``signal`` is ``[n_channels, n_samples]``
     (numpy or tensor); returns the continuous prediction ``[n_out_channels, n_samples]`` (numpy float32
-    unless ``return_tensor``).  ``model(x)`` is called on ``[B, C, W]`` batches in eval mode.
+    unless ``return_tensor``).  ``model(x, **model_kwargs)`` is called on ``[B, C, W]`` batches in eval mode; a tensor
+    in ``model_kwargs`` whose first dimension is the recording's window count is sliced along with the batch.
 
     ``process_group``: the ranks that SHARE this recording (default: all of them, each takes a contiguous range of
     windows and the seams are merged by one all-reduce).  ``dp.NO_GROUP`` = this rank alone processes the whole
@@ -93,7 +94,10 @@ def continuous_inference(model: torch.nn.Module, signal, window_size: int, strid
     while done < shard.n_windows:
         nb = min(batch_windows, shard.n_windows - done)
         first = shard.first_window + done
-        pred = model(windows[first:first + nb], **kw)
+        # a tensor keyword with one entry per window of the recording (odor_ids, cond_emb) is sliced with the batch
+        kwb = {k: (v[first:first + nb] if (torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == total) else v)
+               for k, v in kw.items()}
+        pred = model(windows[first:first + nb], **kwb)
         if isinstance(pred, tuple):
             pred = pred[0]
         if out is None:

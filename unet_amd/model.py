@@ -60,11 +60,6 @@ def _as_ncl(x: Tensor) -> Tensor:
 # ---------------------------------------------------------------------------------------------
 # normalisation (models.py:537-555, 801-817) + activation (+ SE squeeze) on the HIP kernels
 # ---------------------------------------------------------------------------------------------
-def _data_parallel() -> bool:
-    import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-
-
 def _uses_batch_stats(norm: nn.Module) -> bool:
     """BatchNorm that normalises with the statistics of its own input: the conv in front of it can deliver them."""
     return isinstance(norm, nn.BatchNorm1d) and (norm.training or norm.running_mean is None) and torch.is_grad_enabled()
@@ -694,8 +689,9 @@ class _Bottleneck(nn.Sequential):
 
 
 class SessionAdaptiveScaling(nn.Module):
-    """models.py:1998-2068 (scalar mode).  Statistics come from the HIP moments kernel; the
-    64-wide predictor MLP and the final [N, C_out, T] affine are tiny and stay in torch."""
+    """models.py:1998-2068 (scalar mode).  Statistics come from the HIP moments kernel (``unet_ncl_moments``) and the
+    final affine rides the model's output-side layout change (``ops.ToNCLAffineFn`` in ``CondUNet1D``); the 64-wide
+    predictor MLP on [N, 64] stays in torch."""
 
     def __init__(self, n_channels: int, n_input_channels: int = 32, hidden_dim: int = 64):
         super().__init__()
@@ -711,13 +707,21 @@ class SessionAdaptiveScaling(nn.Module):
             self.predictor[-1].bias[:n_channels] = 1.0
             self.predictor[-1].bias[n_channels:] = 0.0
 
-    def forward(self, x: Tensor, raw_input: Tensor) -> Tensor:
-        mean = raw_input.float().mean(dim=-1)
-        std = raw_input.float().std(dim=-1)
+    def scale_params(self, raw_input: Tensor) -> Tuple[Tensor, Tensor]:
+        """gamma, beta [N, C_out] fp32 from the raw input's per-channel mean / unbiased std (models.py:2058-2066)."""
+        if raw_input.is_cuda and not (raw_input.requires_grad and torch.is_grad_enabled()):
+            xin = raw_input if raw_input.dtype in (torch.float32, torch.bfloat16) else raw_input.float()
+            mean, rstd = ops.ncl_moments(xin.contiguous(), 0.0)          # one HIP pass: mean and 1 / std
+            std = rstd.reciprocal()
+        else:     # an input that takes a gradient: torch's differentiable reductions (the reference's graph)
+            mean = raw_input.float().mean(dim=-1)
+            std = raw_input.float().std(dim=-1)
         params = self.predictor(torch.cat([mean, std], dim=-1))
-        gamma = params[:, :self.n_channels].unsqueeze(-1).to(x.dtype)
-        beta = params[:, self.n_channels:].unsqueeze(-1).to(x.dtype)
-        return x * gamma + beta
+        return params[:, :self.n_channels], params[:, self.n_channels:]
+
+    def forward(self, x: Tensor, raw_input: Tensor) -> Tensor:
+        gamma, beta = self.scale_params(raw_input)
+        return x * gamma.unsqueeze(-1).to(x.dtype) + beta.unsqueeze(-1).to(x.dtype)
 
 
 class CondUNet1D(nn.Module):
@@ -848,6 +852,23 @@ class CondUNet1D(nn.Module):
 
     def set_gradient_checkpointing(self, enable: bool = True):
         self.gradient_checkpointing = enable
+
+    def late_grad_parameters(self) -> List[nn.Parameter]:
+        """Parameters whose gradients are produced at the END of backward although they are registered all over the
+        model: the embedding-side FiLM maps (k_proj, v_proj, gate) of every block, which ``forward`` evaluates for
+        all blocks in one node in front of the first block (≈1 M parameters at config B).  A bucketed gradient
+        exchange sends them with the last (tail) bucket (``dp.BucketedGradAllReduce(late_params=...)``)."""
+        if not HOIST_FILM:
+            return []
+        blocks = [self.inc, *self.encoders, *[getattr(d, "block", None) for d in self.decoders]]
+        films = [b.film for b in blocks if isinstance(getattr(b, "film", None), FiLM) and b.film.cond_mode != "none"]
+        if len(films) <= 1:
+            return []
+        out = []
+        for f in films:
+            for w, b, _act, _scale in f.emb_maps():
+                out.extend(t for t in (w, b) if t is not None and t.requires_grad)
+        return out
 
     def train(self, mode: bool = True):
         """Entering training mode drops the inference cache of packed weights (``ops.conv``): fused optimizers update
@@ -1042,11 +1063,11 @@ class CondUNet1D(nn.Module):
         # The FiLM projections depend on the embedding alone: all blocks' k / v / gate maps run as ONE launch here
         # (and one backward launch after the last block's backward) instead of one per block on the critical path.
         # Not under gradient checkpointing, whose recomputation must replay each block's own launches.
-        # Not in a data-parallel job either: the hoisted node's backward runs after the LAST block's, so every block's
-        # k / v / gate gradients would arrive at the very end and hold back the gradient bucket they live in
-        # (dp.BucketedGradAllReduce launches a bucket's all-reduce when its last gradient lands).
+        # In a data-parallel job the hoisted node's backward runs after the LAST block's, so every block's k / v / gate
+        # gradients arrive at the very end: ``late_grad_parameters()`` names them, and dp.BucketedGradAllReduce puts
+        # them into its small tail bucket instead of letting them hold back the buckets of their blocks.
         films = []
-        if HOIST_FILM and emb is not None and not (self.gradient_checkpointing and self.training) and not _data_parallel():
+        if HOIST_FILM and emb is not None and not (self.gradient_checkpointing and self.training):
             blocks = [self.inc, *self.encoders, *[getattr(d, "block", None) for d in self.decoders]]
             films = [b.film for b in blocks if isinstance(getattr(b, "film", None), FiLM) and b.film.cond_mode != "none"]
             if len(films) > 1:
@@ -1097,9 +1118,15 @@ class CondUNet1D(nn.Module):
         else:
             out_nlc = ops.conv(x, self.outc.weight.permute(2, 0, 1), self.outc.bias, ops.geom_conv(3), l, res=res,
                                params=(self.outc.weight, self.outc.bias))
-        out = ops.ToNCLFn.apply(out_nlc, io_dtype)
-        if self.use_adaptive_scaling:
-            out = self.adaptive_scaler(out, raw_input)
+        if self.use_adaptive_scaling and isinstance(self.adaptive_scaler, SessionAdaptiveScaling) \
+                and not (self.adaptive_scaler._forward_hooks or self.adaptive_scaler._forward_pre_hooks):
+            # models.py:3369-3370 folded into the output-side layout change: out = gamma * out + beta in the same pass
+            gamma, beta = self.adaptive_scaler.scale_params(raw_input)
+            out = ops.ToNCLAffineFn.apply(out_nlc, gamma, beta, io_dtype)
+        else:
+            out = ops.ToNCLFn.apply(out_nlc, io_dtype)
+            if self.use_adaptive_scaling:
+                out = self.adaptive_scaler(out, raw_input)
         if return_bottleneck or return_bottleneck_temporal:
             return out, bott
         return out

@@ -1293,6 +1293,52 @@ class ToNCLFn(torch.autograd.Function):
         return dx, None
 
 
+class ToNCLAffineFn(torch.autograd.Function):
+    """y[n, c, t] = gamma[n, c] * x[n, t, c] + beta[n, c]: the model's output-side layout change with
+    SessionAdaptiveScaling's per-(window, channel) affine (models.py:2068) applied on the way -- one pass instead of a
+    transpose followed by torch's broadcast multiply-add over [N, C, T]."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, out_dtype):
+        lib = _lib.load()
+        _need_cuda(x)
+        x = x.contiguous()
+        n, t, c = x.shape
+        ga, be = _f32c(gamma), _f32c(beta)
+        if ga.shape != (n, c) or be.shape != (n, c):
+            raise ValueError(f"gamma / beta must be [{n}, {c}], got {tuple(ga.shape)} / {tuple(be.shape)}")
+        y = torch.empty((n, c, t), dtype=out_dtype, device=x.device)
+        check(lib.unet_nlc_to_ncl(_dt(x), _dt(y), _p(x), _p(None), _p(ga), _p(None), _p(be), _p(y), n, c, t,
+                                  _stream()), "unet_nlc_to_ncl")
+        ctx.save_for_backward(x, ga)
+        ctx.io = (gamma.dtype, beta.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, ga = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, t, c = x.shape
+        g = torch.empty((n, t, c), dtype=x.dtype, device=dy.device)         # dy in the kernels' layout
+        check(lib.unet_ncl_to_nlc(_dt(dy), _dt(g), _p(dy), _p(None), _p(None), _p(g), n, c, t, _stream()),
+              "unet_ncl_to_nlc")
+        dgamma = dbeta = dx = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            # sum_t g and sum_t g * x per (window, channel): the two-sum reduction of the norm backward with the
+            # identity affine (a = 1, b = 0, no activation)
+            ones = torch.ones((n, c), dtype=torch.float32, device=x.device)
+            zeros = torch.zeros_like(ones)
+            g1p, g2p = _part_buf(x, 2)
+            check(lib.unet_affine_act_bwd_reduce(_dt(x), _p(x), _p(g), _p(None), _p(ones), _p(zeros), 0, _p(g1p),
+                                                 _p(g2p), n, t, c, _stream()), "unet_affine_act_bwd_reduce")
+            dbeta = sum_parts(g1p).to(ctx.io[1])
+            dgamma = sum_parts(g2p).to(ctx.io[0])
+        if ctx.needs_input_grad[0]:
+            dx = g * ga.unsqueeze(1).to(g.dtype)
+        return dx, dgamma, dbeta, None
+
+
 class ToNLCFn(torch.autograd.Function):
     """plain layout change NCL -> NLC (used when a block is called directly with an NCL tensor)"""
 

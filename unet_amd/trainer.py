@@ -86,7 +86,8 @@ class Trainer:
                                          capturable=use_graph)
         else:
             raise ValueError(f"optimizer must be 'native' or 'torch', got {optimizer!r}")
-        self.reducer = None if use_graph else BucketedGradAllReduce(model.parameters(), bucket_bytes, process_group)
+        # (a module argument lets the reducer ask for the model's late-gradient parameters: the hoisted FiLM maps)
+        self.reducer = None if use_graph else BucketedGradAllReduce(model, bucket_bytes, process_group)
         self._graphed = None
         self._bucket_bytes = bucket_bytes
         self.nan_check_every = nan_check_every
@@ -138,9 +139,13 @@ class Trainer:
                 else:
                     fwd = lambda o, *i: self.model(o, *i)
                 extra = [self.cond_encoder] if (self.cond_encoder is not None and cond_emb is None) else []
+                # N > 1: ONE graph with the bucket all-reduces inside it, overlapped with the captured backward.  With a
+                # conditioning encoder in the step (its per-rank clip precedes its own small all-reduce) the
+                # two-graph form is the one that exists.
                 self._graphed = GraphedTrainStep(self.model, self._loss, self.opt, [ob] + cond, [tgt],
                                                  clip_norm=self.grad_clip, process_group=self.pg,
-                                                 bucket_bytes=self._bucket_bytes, forward=fwd, extra_modules=extra)
+                                                 bucket_bytes=self._bucket_bytes, forward=fwd, extra_modules=extra,
+                                                 overlap=self.world > 1 and not extra)
             loss = self._graphed([ob] + cond, [tgt])
         else:
             self.reducer.zero_grad()
@@ -259,29 +264,75 @@ class Trainer:
                 "total_time": time.time() - t0}
 
 
+_LOSO_CALLS = 0          # run_loso calls in this process: every rank makes the same calls, so it names a run's keys
+
+
+def _group_store(process_group):
+    """The key-value store behind the process group (TCPStore for torchrun jobs): ``add`` is an atomic fetch-add that
+    every rank can reach without entering a collective -- what a shared job counter needs."""
+    try:
+        from torch.distributed import distributed_c10d as c10d
+        return c10d._get_default_store()
+    except Exception:
+        return None
+
+
 def run_loso(all_sessions: Sequence[str], run_fold: Callable[[LOSOJob], Dict[str, float]], seed: int = 42,
-             n_seeds: int = 3, folds_to_run: Optional[Sequence[int]] = None, process_group=None) -> Dict[str, object]:
+             n_seeds: int = 3, folds_to_run: Optional[Sequence[int]] = None, process_group=None,
+             schedule: str = "dynamic") -> Dict[str, object]:
     """Fold-parallel LOSO (LOSO/runner.py:1046-1177 runs the same jobs serially, one subprocess each).
 
-    Every rank builds the SAME job list (reference order and seeds), takes queue ``rank`` of
-    ``assign_jobs`` and calls ``run_fold(job)`` -> ``{"val_r2", "val_corr", "val_loss"}`` (the
-    test_avg_r2 / test_avg_corr / test_avg_delta of the results JSON, LOSO/runner.py:831-833).  Results
-    are exchanged once (all_gather_object, host side) and aggregated as the reference does:
-    mean over seeds per fold, then mean +- std over folds.
+    Every rank builds the SAME job list (reference order and seeds: ``run_seed = seed + fold * n_seeds + seed_idx``,
+    LOSO/runner.py:619) and calls ``run_fold(job)`` -> ``{"val_r2", "val_corr", "val_loss"}`` (the test_avg_r2 /
+    test_avg_corr / test_avg_delta of the results JSON, LOSO/runner.py:831-833) for the jobs it gets:
+
+    * ``schedule="dynamic"`` (default): a shared counter in the process group's store hands out the jobs in
+      reference order, one at a time, to whichever rank asks next -- folds stop early at very different epochs
+      (patience 15), and a rank whose folds ended early pulls the next job instead of idling.  Which rank runs a job
+      does not enter its result (the job carries its own seed).  Results are published in the same store as they are
+      produced and collected by every rank at the end, so no rank waits inside a collective while others train.
+    * ``schedule="static"``: job k goes to rank k mod world (``folds.assign_jobs``); results travel in one
+      ``all_gather_object``.  Also what a group without a reachable store falls back to.
+
+    Aggregation as in the reference: mean over seeds per fold, then mean +- std over folds.
 
     Ranks run DIFFERENT jobs (and possibly different numbers of them), so ``run_fold`` must not enter a collective
     of ``process_group``: build its ``Trainer`` with ``process_group=dp.NO_GROUP`` (also what ``EarlyStopping`` /
-    ``save_checkpoint`` / ``PooledStats.all_reduce`` take), and give every job its own checkpoint directory.
+    ``save_checkpoint`` / ``PooledStats.all_reduce`` / ``infer.continuous_inference`` take), and give every job its
+    own checkpoint directory.
     """
+    global _LOSO_CALLS
+    if schedule not in ("dynamic", "static"):
+        raise ValueError(f"schedule must be 'dynamic' or 'static', got {schedule!r}")
     world = group_size(process_group)
     rank = group_rank(process_group)
     jobs = loso_jobs(all_sessions, seed, n_seeds, folds_to_run)
-    mine = assign_jobs(jobs, world)[rank]
-    local = [((j.fold_idx, j.seed_idx), run_fold(j)) for j in mine]
-    if world > 1:
-        gathered: List[object] = [None] * world
-        dist.all_gather_object(gathered, local, group=process_group)
-        local = [x for part in gathered for x in part]
+    store = _group_store(process_group) if (world > 1 and schedule == "dynamic") else None
+    _LOSO_CALLS += 1
+    if store is not None:
+        import json
+        from datetime import timedelta
+        members = "-".join(map(str, dist.get_process_group_ranks(process_group or dist.group.WORLD)))
+        prefix = f"unet_amd/loso/{members}/{_LOSO_CALLS}"          # sub-groups running their own LOSO do not collide
+        ran = []
+        while True:
+            k = int(store.add(f"{prefix}/next", 1)) - 1          # atomic: every index is handed out exactly once
+            if k >= len(jobs):
+                break
+            j = jobs[k]
+            store.set(f"{prefix}/res/{k}", json.dumps(run_fold(j)))
+            ran.append(k)
+        keys = [f"{prefix}/res/{k}" for k in range(len(jobs))]
+        if keys:
+            store.wait(keys, timedelta(days=30))                 # other ranks' last jobs may still be training
+        local = [((j.fold_idx, j.seed_idx), json.loads(store.get(key))) for j, key in zip(jobs, keys)]
+    else:
+        mine = assign_jobs(jobs, world)[rank]
+        local = [((j.fold_idx, j.seed_idx), run_fold(j)) for j in mine]
+        if world > 1:
+            gathered: List[object] = [None] * world
+            dist.all_gather_object(gathered, local, group=process_group)
+            local = [x for part in gathered for x in part]
     res = dict(local)
     folds = sorted({j.fold_idx for j in jobs})
     per_fold = {}
