@@ -82,7 +82,7 @@ int unet_conv1d_pack(int32_t dtype, const float* w, int64_t tap_stride, int64_t 
 /* Up to UNET_PACK_MAX_JOBS images in one launch, each described as a unet_conv1d_pack call: a training step packs a
  * conv's forward image together with the transposed image(s) its data gradient will read (the weights are the same
  * until the optimizer runs), which halves the pack launches of a step.  has_tap_src = 0: taps in order. */
-#define UNET_PACK_MAX_JOBS 3
+#define UNET_PACK_MAX_JOBS 4
 typedef struct UnetPackJob {
   const float* w;
   int64_t tap_stride, row_stride, col_stride;
@@ -172,11 +172,12 @@ int unet_rowstats(int32_t dtype, const void* y, float* s1_part, float* s2_part, 
 /* BatchNorm1d training-mode statistics (models.py:540, 804; torch defaults eps 1e-5, momentum 0.1):
  * from the unet_rowstats partials compute, per channel, mean / biased var / rstd, update the running
  * buffers in place (unbiased var; may be NULL), and emit mean/rstd/a/b as [n][c] fp32 with
- * a = gamma*rstd, b = beta - mean*a  (gamma/beta NULL = 1/0). */
+ * a = gamma*rstd, b = beta - mean*a  (gamma/beta NULL = 1/0).  batches_tracked (may be NULL): BatchNorm1d's
+ * num_batches_tracked buffer, incremented by one (torch does it in F.batch_norm's Python wrapper). */
 int unet_bn_finalize_fwd(const float* s1_part, const float* s2_part, int32_t n, int32_t parts, int32_t c,
                          int32_t rows, float eps, const float* gamma, const float* beta,
                          float* running_mean, float* running_var, float momentum, float* mean,
-                         float* rstd, float* a, float* b, void* stream);
+                         float* rstd, float* a, float* b, int64_t* batches_tracked, void* stream);
 /* ... and its backward: from the unet_affine_act_bwd_reduce partials compute dgamma/dbeta [c] and the
  * coefficients ca/cb/cc [n][c] of unet_affine_act_bwd_apply. */
 int unet_bn_finalize_bwd(const float* g1_part, const float* g2_part, int32_t n, int32_t parts, int32_t c,

@@ -331,3 +331,35 @@ def test_adaptive_scaling_kernel_statistics_match_the_differentiable_path():
             continue
         assert rel(grads[0][k], ref) < 1e-3, k
         assert rel(grads[0][k], grads[1][k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("name", ["B_modern_add_bn_gelu", "B2_modern_concat", "modern_group_silu_resconv_oddT"])
+def test_skip_gradient_merged_in_the_data_gradient_epilogue(name):
+    """A skip tensor feeds the next encoder conv and a decoder block: the decoder side parks its gradient
+    (ops.StashGradFn) and the encoder conv's data-gradient kernel adds it in its epilogue instead of autograd running a
+    full-tensor add.  Same gradients as with autograd's own accumulation (fp32: to rounding), and both match the
+    reference (the golden tests above run with the merge on)."""
+    from unet_amd import ops
+    g = Golden(name)
+    grads = []
+    hits = []
+    for fuse in (True, False):
+        ops.SKIP_GRAD_FUSE = fuse
+        try:
+            model = _build(g)
+            model.train()
+            before = ops.SKIP_GRAD_HITS
+            ob = g.t("ob").cuda().requires_grad_(True)
+            pred = model(ob, **_kw(g))
+            F.l1_loss(pred[..., g.lo:g.hi], g.t("target").cuda()[..., g.lo:g.hi]).backward()
+            hits.append(ops.SKIP_GRAD_HITS - before)
+            grads.append((ob.grad.clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            ops.SKIP_GRAD_FUSE = True
+    assert hits[0] == g.cfg.get("n_downsample", 2) and hits[1] == 0
+    assert rel(grads[0][0], grads[1][0]) < 1e-5
+    for k, v in grads[1][1].items():
+        if v.abs().max().item() < 1e-7:
+            continue
+        assert rel(grads[0][1][k], v) < 1e-5, k
+    assert rel(grads[0][0], g.t("grad_ob")) < 1e-3

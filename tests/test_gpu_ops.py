@@ -363,8 +363,10 @@ def test_pack_multi_images_equal_single_packs(dtype, stride):
     for img, j in zip(many, jobs):
         assert torch.equal(img, ops.pack_weights(w, dt, **j))
     assert torch.equal(ops.pack_weights_multi(w, dt, jobs[:2])[1], many[1])
+    four = ops.pack_weights_multi(w, dt, jobs + [dict(jobs[0], w=w * 2.0)])      # a job may bring its own weights
+    assert torch.equal(four[3], ops.pack_weights(w * 2.0, dt, **jobs[0])) and torch.equal(four[2], many[2])
     with pytest.raises(ValueError):
-        ops.pack_weights_multi(w, dt, jobs + jobs[:1])
+        ops.pack_weights_multi(w, dt, jobs + jobs[:2])
 
     n, l = 3, 200
     l_out = (l + stride - 1) // stride if stride == 2 else l

@@ -27,7 +27,7 @@ class PackJob(C.Structure):
     ]
 
 
-PACK_MAX_JOBS = 3
+PACK_MAX_JOBS = 4
 OPT_MAX_TENSORS = 256
 
 
@@ -96,7 +96,7 @@ _SIGNATURES = {
     "unet_affine_act_se_bwd_reduce": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _vp] + _row_args),
     "unet_se_combine": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "unet_affine_act_se_bwd_apply": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp] + _row_args),
-    "unet_bn_finalize_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "unet_bn_finalize_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "unet_bn_finalize_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "unet_reduce_rows": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "unet_reduce_parts": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),

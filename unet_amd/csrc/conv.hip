@@ -866,13 +866,14 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const PackK p) { pack_jo
 
 // up to three images in one launch (a conv's forward image and the transposed images its data gradients will need):
 // every block walks the jobs in turn, so nothing in a job's loop depends on which job it is
-struct PackM { PackK k[3]; int n; };
+struct PackM { PackK k[UNET_PACK_MAX_JOBS]; int n; };
 
 template <bool F32>
 __global__ __launch_bounds__(256) void conv_pack_multi_kernel(const PackM p) {
   pack_job<F32>(p.k[0]);
-  if (p.n > 1) pack_job<F32>(p.k[1]);
-  if (p.n > 2) pack_job<F32>(p.k[2]);
+#pragma unroll
+  for (int i = 1; i < UNET_PACK_MAX_JOBS; ++i)
+    if (p.n > i) pack_job<F32>(p.k[i]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1193,10 +1194,16 @@ __device__ __forceinline__ void conv_wgrad2_body(const Wg2K& p) {
     char* sx = sdy + WG2_DY_BYTES;
 #pragma unroll
     for (int i = 0; i < WG2_BKP / 16; ++i)
+#if defined(WG2_ABLATE) && WG2_ABLATE >= 2      // diagnostic builds only (profiles/r03_kernel_experiments.txt): no dy loads
+      if (buf < 0)
+#endif
       __builtin_amdgcn_raw_ptr_buffer_load_lds(dsrc, (__attribute__((address_space(3))) void*)(sdy + (wave * (WG2_BKP / 16) + i) * 1024),
                                                16, dy_voff[i] + dy_io, 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < WG2_XROWS / 16; ++i)
+#if defined(WG2_ABLATE) && WG2_ABLATE >= 1      // ... no x loads
+      if (buf < 0)
+#endif
       if ((wave + i * (THREADS / 64)) * 4 < xrows)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xsr, (__attribute__((address_space(3))) void*)(sx + (wave + i * (THREADS / 64)) * 1024),
                                                  16, x_voff[i] + x_io, 0, 0, 0);
@@ -1704,7 +1711,7 @@ extern "C" int unet_conv1d_pack_multi(int32_t dtype, const UnetPackJob* jobs, in
   PackM m;
   m.n = n_jobs;
   long long most = 0;
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < UNET_PACK_MAX_JOBS; ++i) {
     const UnetPackJob& j = jobs[i < n_jobs ? i : 0];     // unused slots repeat job 0 (never run: n guards them)
     if (fill_pack(&m.k[i], dtype, j.w, j.tap_stride, j.row_stride, j.col_stride, j.n_taps,
                   j.has_tap_src ? j.tap_src : nullptr, j.row_lo, j.rows, j.col_lo, j.c1, j.c2, j.packed)) return -1;

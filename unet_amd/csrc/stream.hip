@@ -661,9 +661,10 @@ __global__ __launch_bounds__(CS_THREADS) void bn_finalize_fwd_kernel(const float
                                                                      double count, float eps, const float* gamma,
                                                                      const float* beta, float* run_mean, float* run_var,
                                                                      float momentum, float* mean_o, float* rstd_o, float* a_o,
-                                                                     float* b_o) {
+                                                                     float* b_o, long long* batches_tracked) {
   __shared__ double red[2 * CS_SEG * CS_CH];
   __shared__ float coef[4][CS_CH];
+  if (batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *batches_tracked += 1;
   const int cl = threadIdx.x % CS_CH, seg = threadIdx.x / CS_CH;
   const int ch = blockIdx.x * CS_CH + cl;
   const float* const src[2] = {s1p, s2p};
@@ -1183,13 +1184,13 @@ extern "C" int unet_nlc_to_ncl(int32_t dtype, int32_t out_dtype, const void* x, 
 extern "C" int unet_bn_finalize_fwd(const float* s1_part, const float* s2_part, int32_t n, int32_t parts, int32_t c,
                                     int32_t rows, float eps, const float* gamma, const float* beta,
                                     float* running_mean, float* running_var, float momentum, float* mean,
-                                    float* rstd, float* a, float* b, void* stream) {
+                                    float* rstd, float* a, float* b, int64_t* batches_tracked, void* stream) {
   UNET_REQUIRE(s1_part && s2_part && mean && rstd && a && b && n > 0 && parts > 0 && c > 0 && rows > 0,
                "bn_finalize_fwd: bad arguments");
   UNET_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_fwd: running stats must come in pairs");
   hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(c, CS_CH)), dim3(CS_THREADS), 0, static_cast<hipStream_t>(stream), s1_part,
                      s2_part, n, parts, c, (double)n * rows, eps, gamma, beta, running_mean, running_var, momentum, mean,
-                     rstd, a, b);
+                     rstd, a, b, reinterpret_cast<long long*>(batches_tracked));
   UNET_LAUNCH_CHECK("bn_finalize_fwd");
   return 0;
 }

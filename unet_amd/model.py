@@ -116,9 +116,13 @@ def _norm_act(y: Tensor, norm: nn.Module, act_id: int, want_pool: bool, se=None)
         if use_batch:
             track = norm.training and norm.track_running_stats and norm.running_mean is not None
             mom = norm.momentum
+            nbt = None
             if track:
-                with torch.no_grad():
-                    norm.num_batches_tracked += 1
+                nbt = norm.num_batches_tracked
+                if mom is None or nbt is None or not nbt.is_cuda:
+                    with torch.no_grad():
+                        norm.num_batches_tracked += 1
+                    nbt = None           # counted here; otherwise the finalisation kernel increments it (no launch)
                 if mom is None:  # cumulative moving average (not used by the reference; needs a host read)
                     mom = 1.0 / float(norm.num_batches_tracked)
             rm = norm.running_mean if track else None
@@ -127,9 +131,9 @@ def _norm_act(y: Tensor, norm: nn.Module, act_id: int, want_pool: bool, se=None)
                 raise TypeError("BatchNorm running buffers must be contiguous fp32")
             if se is not None:
                 return ops.BatchNormActSEFn.apply(y, norm.weight, norm.bias, rm, rv, float(mom or 0.0), float(norm.eps),
-                                                  act_id, se.fc[0].weight, se.fc[2].weight)
+                                                  act_id, se.fc[0].weight, se.fc[2].weight, nbt)
             return ops.BatchNormActFn.apply(y, norm.weight, norm.bias, rm, rv, float(mom or 0.0), float(norm.eps),
-                                            act_id, want_pool)
+                                            act_id, want_pool, nbt)
         else:
             mean_c = norm.running_mean.double()
             rstd_c = torch.rsqrt(norm.running_var.double() + norm.eps)
@@ -1087,8 +1091,16 @@ class CondUNet1D(nn.Module):
                 return checkpoint(block.forward_nlc, *a, use_reentrant=False)
             return block.forward_nlc(*a)
 
+        # A skip tensor has two consumers (the next encoder block's conv and a decoder block); instead of autograd's
+        # full-tensor add of their two gradients, the decoder side parks its gradient and the encoder conv's
+        # data-gradient kernel adds it in its epilogue (ops.GradStash).  Gradient checkpointing keeps working: the
+        # stash is created and parked out here, outside the checkpointed block functions, and a recomputation only
+        # re-arms the same stash.
+        fuse = True
         skips = [_HookedCall.run(self.inc, run, x0, emb)]
+        stashes = []
         for enc in self.encoders:
+            stashes.append(ops.stash_for(skips[-1]) if fuse else None)
             skips.append(_HookedCall.run(enc, run, skips[-1], emb))
 
         bottleneck = _HookedCall.run(self.mid, lambda blk, x: blk.forward_nlc(x), skips[-1])
@@ -1101,7 +1113,11 @@ class CondUNet1D(nn.Module):
 
         x = bottleneck
         for i, dec in enumerate(self.decoders):
-            x = _HookedCall.run(dec, run, x, skips[self.n_downsample - i - 1], emb)
+            j = self.n_downsample - i - 1
+            skip = skips[j]
+            if stashes[j] is not None and stashes[j].armed:
+                skip = ops.StashGradFn.apply(skip, stashes[j])
+            x = _HookedCall.run(dec, run, x, skip, emb)
 
         l = x.shape[1]
         if self.use_residual:

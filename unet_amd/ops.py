@@ -335,18 +335,20 @@ def pack_weights(w: Tensor, dtype: int, *, transpose: bool, tap_src: Optional[Se
 
 
 def pack_weights_multi(w: Tensor, dtype: int, jobs: Sequence[dict]) -> List[Tensor]:
-    """Several ``pack_weights`` images of one weight tensor in ONE launch (``jobs``: the keyword arguments of each)."""
+    """Several ``pack_weights`` images in ONE launch (``jobs``: the keyword arguments of each; a job may name its own
+    weight tensor under ``"w"``, otherwise it packs ``w``)."""
     lib = _lib.load()
     if not 1 <= len(jobs) <= _lib.PACK_MAX_JOBS:
         raise ValueError(f"1..{_lib.PACK_MAX_JOBS} images per launch, got {len(jobs)}")
     arr = (_lib.PackJob * len(jobs))()
     outs = []
-    ts, s1, s2 = w.stride()
     for a, j in zip(arr, jobs):
+        wj = j.get("w", w)
+        ts, s1, s2 = wj.stride()
         out = torch.empty(lib.unet_conv1d_packed_bytes(dtype, j["n_taps"], j["rows"], j["c1"], j["c2"]),
-                          dtype=torch.uint8, device=w.device)
+                          dtype=torch.uint8, device=wj.device)
         outs.append(out)
-        a.w, a.tap_stride = w.data_ptr(), ts
+        a.w, a.tap_stride = wj.data_ptr(), ts
         a.row_stride, a.col_stride = (s2, s1) if j["transpose"] else (s1, s2)
         a.n_taps, a.has_tap_src = j["n_taps"], int(j["tap_src"] is not None)
         if j["tap_src"] is not None:
@@ -480,12 +482,60 @@ def _take_colsum(dy: Tensor) -> Optional[Tensor]:
 DUAL_PACK = os.environ.get("UNET_DUAL_PACK", "1") != "0"     # 0: one pack launch per image (A/B measurements)
 
 
+class GradStash:
+    """Hand-off of ONE gradient between the two consumers of a skip tensor (CondUNet1D: an encoder output feeds the
+    next encoder block's conv AND a decoder block).  Autograd would add the two gradients with a full-tensor pass of
+    its own (3 touches); instead the decoder-side consumer parks its gradient here (``StashGradFn``) and the
+    encoder-side conv adds it in the epilogue of its data-gradient kernel (``ConvFn.backward``: ``res``).
+    Either order of the two backward calls is correct: if the conv's backward ran first (``consumed``), the parked
+    path hands its gradient to autograd as usual."""
+    __slots__ = ("g", "armed", "consumed")
+
+    def __init__(self):
+        self.g, self.armed, self.consumed = None, False, False
+
+
+SKIP_GRAD_FUSE = os.environ.get("UNET_SKIP_GRAD_FUSE", "1") != "0"     # 0: autograd's own accumulation (A/B runs)
+SKIP_GRAD_HITS = 0          # diagnostic: gradients merged in a data-gradient epilogue
+
+
+class StashGradFn(torch.autograd.Function):
+    """Identity whose backward parks the incoming gradient in ``stash`` (and reports none to autograd)."""
+
+    @staticmethod
+    def forward(ctx, x, stash: GradStash):
+        ctx.stash = stash
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        st = ctx.stash
+        if st.consumed:          # the conv's backward has already run (or ran in an earlier backward over this graph)
+            return g, None
+        st.g = g if st.g is None else st.g + g
+        return None, None
+
+
+def stash_for(x: Tensor) -> Optional[GradStash]:
+    """Mark ``x`` as a tensor whose next conv consumer (``ops.conv(x, ...)``) may take a second gradient through its
+    data-gradient epilogue; returns the stash (``armed`` once such a consumer has accepted it)."""
+    if not (SKIP_GRAD_FUSE and torch.is_grad_enabled() and x.requires_grad):
+        return None
+    st = GradStash()
+    x._unet_grad_stash = st
+    return st
+
+
 class ConvFn(torch.autograd.Function):
     """y = conv(geom; [x1 | x2], w[J, Cout, C1+C2], bias) (+ res).  See include/unet_hip.h."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w, bias, res, geom: ConvGeom, l_out: int, want_stats: bool = False):
+    def forward(ctx, x1, x2, w, bias, res, geom: ConvGeom, l_out: int, want_stats: bool = False,
+                x1_stash: Optional[GradStash] = None):
         _need_cuda(x1)
+        ctx.x1_stash = x1_stash if (x1_stash is not None and ctx.needs_input_grad[0]) else None
+        if ctx.x1_stash is not None:
+            ctx.x1_stash.armed = True
         x1 = _nlc_ok(x1)
         x2 = _nlc_ok(x2) if x2 is not None else None
         res = _nlc_ok(res) if res is not None else None
@@ -549,10 +599,20 @@ class ConvFn(torch.autograd.Function):
             if ctx.w_dtype != torch.float32:
                 dw = dw.to(ctx.w_dtype)
         if ctx.needs_input_grad[0]:
-            dx1 = conv_dgrad_raw(geom, wf, dy, l_in, 0, c1, wp=ctx.wp_d1)
+            extra = None
+            st = ctx.x1_stash
+            if st is not None:       # the gradient the tensor's OTHER consumer parked: merged in the kernel's epilogue
+                global SKIP_GRAD_HITS
+                extra, st.g, st.consumed = st.g, None, True
+            fused = extra is not None and extra.shape == x1.shape and extra.dtype == dy.dtype and extra.is_contiguous()
+            dx1 = conv_dgrad_raw(geom, wf, dy, l_in, 0, c1, wp=ctx.wp_d1, res=extra if fused else None)
+            if fused:
+                SKIP_GRAD_HITS += 1
+            elif extra is not None:
+                dx1 = dx1 + extra.to(dx1.dtype)
         if ctx.has_x2 and ctx.needs_input_grad[1]:
             dx2 = conv_dgrad_raw(geom, wf, dy, l_in, c1, c2, wp=ctx.wp_d2)
-        return dx1, dx2, dw, db, dres, None, None, None
+        return dx1, dx2, dw, db, dres, None, None, None, None
 
 
 # Packed-weight cache for INFERENCE.  A training step must repack every weight (the optimizer has just changed it; the
@@ -620,7 +680,7 @@ def conv(x1: Tensor, w, bias: Optional[Tensor], geom: ConvGeom, l_out: int, x2: 
         wp, b32, c_out = packed_for_inference(("conv", geom, c1, c2), params, dt, build)
         return conv_forward_raw(geom, x1, x2, wp, b32, res, l_out, c_out)
     wv, bv = w() if callable(w) else (w, bias)
-    return ConvFn.apply(x1, x2, wv, bv, res, geom, l_out, want_stats)
+    return ConvFn.apply(x1, x2, wv, bv, res, geom, l_out, want_stats, getattr(x1, "_unet_grad_stash", None))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -774,13 +834,23 @@ class AffineActFn(torch.autograd.Function):
         return dy, dgamma, dbeta, None, None, None
 
 
+def _counter_ok(t: Optional[Tensor]) -> Optional[Tensor]:
+    """BatchNorm's ``num_batches_tracked`` (int64 scalar on the GPU), incremented by the finalisation kernel itself
+    instead of a launch of its own per norm layer and step."""
+    if t is None:
+        return None
+    if t.dtype != torch.int64 or t.numel() != 1 or not t.is_cuda:
+        raise TypeError("num_batches_tracked must be an int64 scalar on the GPU")
+    return t
+
+
 class BatchNormActFn(torch.autograd.Function):
     """z = act(BatchNorm1d_train(y)) (+ pooled sum of z): statistics, running-buffer update and the
     affine coefficients come from ONE finalisation kernel (unet_bn_finalize_fwd); backward likewise."""
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, momentum: float, eps: float, act_id: int,
-                want_pool: bool):
+                want_pool: bool, batches_tracked: Optional[Tensor] = None):
         lib = _lib.load()
         _need_cuda(y)
         y = y.contiguous()
@@ -798,7 +868,7 @@ class BatchNormActFn(torch.autograd.Function):
         bf = _f32c(beta) if beta is not None else None
         check(lib.unet_bn_finalize_fwd(_p(s1p), _p(s2p), n, s1p.shape[1], c, rows, eps, _p(gf), _p(bf),
                                        _p(running_mean), _p(running_var), momentum, _p(mean), _p(rstd), _p(a), _p(b),
-                                       st), "unet_bn_finalize_fwd")
+                                       _p(_counter_ok(batches_tracked)), st), "unet_bn_finalize_fwd")
         z = torch.empty_like(y)
         pbuf = (s1p if hint is None else _part_buf(y)[0]) if want_pool else None  # own partial buffer no longer needed: reuse
         check(lib.unet_affine_act_fwd(dt, _p(y), _p(a), _p(b), act_id, _p(z), _p(pbuf), n, rows, c, st),
@@ -834,7 +904,7 @@ class BatchNormActFn(torch.autograd.Function):
         _offer_colsum(dy, g1p)       # g1p is free again: bn_finalize_bwd has consumed it
         dgamma = dgb[0].to(ctx.gdtype) if ctx.has_affine else None
         dbeta = dgb[1].to(ctx.gdtype) if ctx.has_affine else None
-        return dy, dgamma, dbeta, None, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def se_gate(pool_sum: Tensor, w0: Tensor, w2: Tensor, rows: int) -> Tensor:
@@ -855,7 +925,8 @@ class BatchNormActSEFn(torch.autograd.Function):
     of SE-excite backward + norm reduction + norm apply."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum: float, eps: float, act_id: int, w0, w2):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum: float, eps: float, act_id: int, w0, w2,
+                batches_tracked: Optional[Tensor] = None):
         lib = _lib.load()
         _need_cuda(y)
         y = y.contiguous()
@@ -873,7 +944,7 @@ class BatchNormActSEFn(torch.autograd.Function):
         bf = _f32c(beta) if beta is not None else None
         check(lib.unet_bn_finalize_fwd(_p(s1p), _p(s2p), n, s1p.shape[1], c, rows, eps, _p(gf), _p(bf),
                                        _p(running_mean), _p(running_var), momentum, _p(mean), _p(rstd), _p(a), _p(b),
-                                       st), "unet_bn_finalize_fwd")
+                                       _p(_counter_ok(batches_tracked)), st), "unet_bn_finalize_fwd")
         pbuf = s1p if hint is None else _part_buf(y)[0]
         check(lib.unet_affine_pool(dt, _p(y), _p(a), _p(b), act_id, _p(pbuf), n, rows, c, st), "unet_affine_pool")
         pool = sum_parts(pbuf)
@@ -923,7 +994,7 @@ class BatchNormActSEFn(torch.autograd.Function):
         _offer_colsum(dy, bsum)
         dgamma = dgb[0].to(ctx.gdtype) if ctx.has_affine else None
         dbeta = dgb[1].to(ctx.gdtype) if ctx.has_affine else None
-        return dy, dgamma, dbeta, None, None, None, None, None, dw0.to(ctx.wdtypes[0]), dw2.to(ctx.wdtypes[1])
+        return dy, dgamma, dbeta, None, None, None, None, None, dw0.to(ctx.wdtypes[0]), dw2.to(ctx.wdtypes[1]), None
 
 
 def norm_act_se_inference(y: Tensor, a: Tensor, b: Tensor, act_id: int, w0: Tensor, w2: Tensor) -> Tensor:
@@ -1051,9 +1122,18 @@ class FilmFn(torch.autograd.Function):
         wqf, wof = wq.detach().float(), wo.detach().float()          # [1, C, C] views of the 1x1 conv weights
         kf, vf, gf = _f32c(kk), _f32c(v), _f32c(g)
         pk = lambda wf: pack_weights(wf, dt, transpose=False, tap_src=None, n_taps=1, row_lo=0, rows=c, c1=c, c2=0)
+        ctx.wp_dq = ctx.wp_do = None
         if _cacheable((wq, bq, wo, bo)):
             wqp, bq32, wop, bo32 = packed_for_inference(("film", c), (wq, bq, wo, bo), dt,
                                                         lambda: (pk(wqf), _f32c(bq), pk(wof), _f32c(bo)))
+        elif DUAL_PACK and torch.is_grad_enabled() and _lib.PACK_MAX_JOBS >= 4:
+            # the two forward images and the two transposed images backward will read, in ONE launch (a pack is
+            # launch-bound: four 5 us launches per block and step otherwise)
+            fj = dict(transpose=False, tap_src=None, n_taps=1, row_lo=0, rows=c, c1=c, c2=0)
+            wqp, wop, ctx.wp_dq, ctx.wp_do = pack_weights_multi(wqf, dt, [
+                dict(fj, w=wqf), dict(fj, w=wof), dict(_dgrad_pack_job(g1, wqf, 0, c), w=wqf),
+                dict(_dgrad_pack_job(g1, wof, 0, c), w=wof)])
+            bq32, bo32 = _f32c(bq), _f32c(bo)
         else:
             wqp, bq32, wop, bo32 = pk(wqf), _f32c(bq), pk(wof), _f32c(bo)
         q = conv_forward_raw(g1, z, None, wqp, bq32, None, rows, c)
@@ -1080,14 +1160,14 @@ class FilmFn(torch.autograd.Function):
               "unet_gated_add_bwd")
         dwo = conv_wgrad_raw(g1, h, None, d_o, c)
         dbo = _reduce_all_parts(dop)                      # bias gradient of out_proj from the same pass
-        dh = conv_dgrad_raw(g1, wof, d_o, rows, 0, c)
+        dh = conv_dgrad_raw(g1, wof, d_o, rows, 0, c, wp=ctx.wp_do)
         dq = torch.empty_like(q)
         dkp, dvp, dqp = _part_buf(q, 3)
         check(lib.unet_film_softmax_bwd(dt, _p(q), _p(dh), _p(kf), _p(vf), _p(dq), _p(dkp), _p(dvp), _p(dqp), n, rows, c,
                                         st), "unet_film_softmax_bwd")
         dwq = conv_wgrad_raw(g1, z, None, dq, c)
         dbq = _reduce_all_parts(dqp)                      # bias gradient of q_proj (same pass for C <= 512)
-        dz = conv_dgrad_raw(g1, wqf, dq, rows, 0, c, res=dout) if ctx.needs_input_grad[0] else None
+        dz = conv_dgrad_raw(g1, wqf, dq, rows, 0, c, res=dout, wp=ctx.wp_dq) if ctx.needs_input_grad[0] else None
         t = ctx.dtypes
         return (dz, dwq.to(t[0]), dbq.to(t[1]), dwo.to(t[2]), dbo.to(t[3]), sum_parts(dkp).to(t[4]),
                 sum_parts(dvp).to(t[5]), sum_parts(dgp).to(t[6]))
