@@ -351,3 +351,31 @@ def test_tile_width_variants_agree():
         os.environ.pop("UNET_CONV_BN", None)
     assert rel(outs["128"], outs[""]) < 1e-6
     assert rel(outs["64"], outs[""]) < 1e-6
+
+
+def test_wide_tile_of_few_tap_convs_agrees_with_the_128_wide_tile():
+    """conv_fwd2_kernel_256 (k = 3 and transposed convs at unit stride: 256 positions per tile, halo tile single-buffered)
+    against the 128-wide tile on the bottleneck conv of config B (N = 64) and on a transposed conv with a residual."""
+    from unet_amd import ops
+    torch.manual_seed(4)
+    x = torch.randn(64, 1024, 1024, device="cuda").bfloat16()
+    w = (torch.randn(3, 1024, 1024, device="cuda") / 55.0)
+    b = torch.randn(1024, device="cuda") * 0.1
+    xt = torch.randn(8, 1000, 512, device="cuda").bfloat16()                 # ragged: 1000 = 3 x 256 + 232
+    geom_t, kidx = ops.geom_convt_k4s2p1()
+    wt = torch.randn(4, 256, 512, device="cuda") / 32.0
+    res = torch.randn(8, 2000, 256, device="cuda").bfloat16()
+    outs = {}
+    try:
+        for bn in ("", "128"):
+            if bn:
+                os.environ["UNET_CONV_BN"] = bn
+            else:
+                os.environ.pop("UNET_CONV_BN", None)
+            with torch.no_grad():
+                outs[bn] = (ops.conv(x, w, b, ops.geom_conv(3), 1024).float(),
+                            ops.conv(xt, wt, None, geom_t, 2000, res=res).float())
+    finally:
+        os.environ.pop("UNET_CONV_BN", None)
+    assert rel(outs[""][0], outs["128"][0]) < 1e-6
+    assert rel(outs[""][1], outs["128"][1]) < 1e-6

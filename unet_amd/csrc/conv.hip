@@ -572,6 +572,7 @@ __device__ __forceinline__ void conv_fwd2_body(const ConvK& p) {
 __global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_128(const ConvK p) { conv_fwd2_body<128>(p); }
 __global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_64(const ConvK p) { conv_fwd2_body<64>(p); }
 __global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_192(const ConvK p) { conv_fwd2_body<192>(p); }
+__global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_256(const ConvK p) { conv_fwd2_body<256>(p); }
 __global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_128h(const ConvK p) { conv_fwd2_body<128, true>(p); }
 __global__ __launch_bounds__(THREADS, 2) void conv_fwd2_kernel_192h(const ConvK p) { conv_fwd2_body<192, true>(p); }
 
@@ -1600,8 +1601,9 @@ int launch_fwd2(ConvK& k, int rmax, hipStream_t st) {
   k.xdb = (2 * WTILE_BYTES + 2 * (size_t)xbytes <= 80 * 1024) ? 1 : 0;
   const size_t lds = 2 * WTILE_BYTES + (size_t)xbytes * (k.xdb ? 2 : 1);
   // one source of at most 32 channels: the variant without the second k-step (BN 128 / 192)
-  const bool half = BN != 64 && k.c2 == 0 && k.c1 <= 32;
-  void (*kern)(const ConvK) = BN == 192 ? (half ? conv_fwd2_kernel_192h : conv_fwd2_kernel_192)
+  const bool half = BN != 64 && BN != 256 && k.c2 == 0 && k.c1 <= 32;
+  void (*kern)(const ConvK) = BN == 256 ? conv_fwd2_kernel_256
+                            : BN == 192 ? (half ? conv_fwd2_kernel_192h : conv_fwd2_kernel_192)
                             : BN == 128 ? (half ? conv_fwd2_kernel_128h : conv_fwd2_kernel_128)
                                         : conv_fwd2_kernel_64;
   static bool attr_set[2] = {false, false};
@@ -1821,6 +1823,30 @@ int conv_fwd_impl(const UnetConvDesc* d, const void* x1, const void* x2, const v
       // 192 positions per tile (2/3 of the weight bytes and LDS-DMA instructions per FLOP) for many-tap convs when
       // the halo tile still leaves two workgroups per CU and the last, partial tile wastes under 4 % of the work
       const char* envb = getenv("UNET_CONV_BN");
+      // 256 positions per tile for convs with few taps per phase (k = 3, the transposed conv's two taps per phase):
+      // their blocks live for a handful of (K-chunk, tap) steps, the weight tiles are most of what a step stages and
+      // every step pays a barrier; the wide tile halves the weight bytes and the barriers per FLOP (128 accumulator
+      // registers per lane, the halo tile single-buffered so that two workgroups still fit a CU)
+      // (unit stride only: the stride-2 data gradient of the transposed conv measured 3 % slower, scripts/bench_conv.py)
+      bool want256 = d->n_taps <= 4 * d->up && d->stride == 1 && d->c_out >= 128 && !(envb && atoi(envb) != 256) &&
+                     !(k.c2 == 0 && k.c1 <= 32);
+      for (int r = 0; r < d->up && want256; ++r)
+        want256 = ph.mcount[r] > 0 && (long long)cdiv(ph.mcount[r], 256) * 256 * 100 <= (long long)ph.mcount[r] * 104;
+      if (want256) {
+        TileGeom tg2;
+        tile_geom(d, ph, 256, &tg2);
+        const int pieces = (tg2.rmax + 7) / 8;
+        if (pieces <= 4 * F2_MAXP && 2 * WTILE_BYTES + (size_t)pieces * 1024 <= 80 * 1024) {
+          for (int r = 0; r < 2; ++r) {
+            k.ptiles[r] = (r < d->up) ? cdiv(ph.mcount[r], 256) : 0;
+            for (int c = 0; c < 2; ++c) { k.seg_rows[r][c] = tg2.seg_rows[r][c]; k.seg_q0[r][c] = tg2.seg_q0[r][c]; }
+          }
+          for (int j = 0; j < UNET_MAX_TAPS; ++j) k.tap_row[j] = tg2.tap_row[j];
+          g_last_variant = UNET_VARIANT_FWD_TILED;
+          if (want_stats) { k.s1 = s1_part; k.s2 = s2_part; *parts_out = k.ptiles[0]; }
+          return launch_fwd2<256>(k, tg2.rmax, st);
+        }
+      }
       bool want = d->n_taps >= 8 && !(envb && atoi(envb) == 128);
       for (int r = 0; r < d->up && want; ++r)
         want = ph.mcount[r] > 0 && (long long)cdiv(ph.mcount[r], 192) * 192 * 100 <= (long long)ph.mcount[r] * 104;
