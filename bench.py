@@ -50,7 +50,7 @@ WORKLOADS = {
 T = 4096
 CROP = (500, 4500)
 BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16
-TRAFFIC_FILE = "r02_hbm_traffic.json"
+TRAFFIC_FILE = "r03_hbm_traffic.json"
 KERNEL_DESCR = {
     "conv_fwd2_kernel": "conv_fwd2_kernel_128/_192 (bf16 implicit-GEMM tap-list conv, forward and data-grad launches)",
     "conv_stream_kernel": "conv_stream_kernel (bf16 single-tap conv, persistent 256x128 tiles)",
@@ -159,7 +159,7 @@ def main():
         torch.cuda.set_device(0)
         dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29733", world_size=1, rank=0,
                                 device_id=torch.device("cuda", 0))
-        args.eager = True
+        args.eager = not args.graph_overlap      # --dp-selftest --graph-overlap: the N > 1 DEFAULT path on one GPU
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -223,7 +223,8 @@ def main():
             from unet_amd.graphs import GraphedTrainStep
             fwd = (lambda o, i: model(o, i, cond_emb=enc(o))) if enc is not None else None
             graphed = GraphedTrainStep(model, loss_fn, opt, [ob, ids], [tgt], clip_norm=5.0, forward=fwd,
-                                       extra_modules=[enc] if enc is not None else [], overlap=args.graph_overlap)
+                                       extra_modules=[enc] if enc is not None else [], overlap=args.graph_overlap,
+                                       force_collectives=args.dp_selftest)
             mode = "hipgraph+rccl-in-graph" if graphed.overlap else "hipgraph"
         except Exception as e:  # capture unsupported in this environment: run the same step eagerly
             import traceback

@@ -10,7 +10,8 @@ import re
 import sys
 
 tag = sys.argv[1]
-KERNELS = ["conv_fwd2_kernel_192", "conv_fwd2_kernel_128", "conv_fwd2_kernel_64", "conv_stream_kernel", "conv_wgrad2_kernel", "conv_fwd_kernel",
+KERNELS = ["conv_fwd2_kernel_256", "conv_fwd2_kernel_192", "conv_fwd2_kernel_128", "conv_fwd2_kernel_64", "conv_stream_kernel", "conv_wgrad2s_kernel",
+           "conv_wgrad2_kernel", "conv_wgrad3_kernel", "conv_fwd_kernel",
            "conv_wgrad_kernel", "slab_reduce_kernel", "rowstream_kernel", "film_softmax", "merge_taps", "conv_pack_kernel"]
 
 

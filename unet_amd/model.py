@@ -232,8 +232,9 @@ class CrossFrequencyCouplingAttentionV2(nn.Module):
     bf16: the same linear operator as one library GEMM, see ``_band_operator``; no transposes), the per-band projections and out_proj run on the HIP conv kernels (the grouped Conv1d is five
     independent C x C convs on strided views of one buffer), and in bf16 the 25 attention products, their
     coupling-weighted sum and the concatenation are ONE launch of the band-pair flash kernel (``csrc/attn.hip``,
-    head_dim = C/4 = 256 at config B, 107 GFLOP per window; backward = 3 launches).  fp32 parity runs evaluate the
-    same products with ``scaled_dot_product_attention``.
+    head_dim = C/4 = 256 at config B, 107 GFLOP per window; backward = 3 launches).  fp32 runs take the same route
+    through the exact-fp32 flash kernels of ``csrc/attn_f32.hip``; ``scaled_dot_product_attention`` is left only for
+    head sizes neither kernel family takes (not a multiple of 8 / 4, or above 256).
     """
 
     def __init__(self, channels: int, n_heads: int = 4, sample_rate: float = 1000.0, bands=None, chunk_size: int = 256,
