@@ -133,8 +133,8 @@ int unet_conv1d_wgrad(const UnetConvDesc* d, const void* x1, const void* x2, con
  * array built into the library instead of a caller-provided workspace: UNET_NOALLOC_SCRATCH_BYTES per GPU the
  * library runs on, held until the process ends.  Where the slabs unet_conv1d_wgrad would use fit the array, the
  * kernel and the split count are the same and dw is bit-identical.  One exception: a single-tap conv whose
- * 256 x 256-tile kernel (conv_wgrad3) needs more slabs than fit while the paired kernel's fit (e.g. C = 512, 1x1:
- * 64 MiB against 32) runs the paired kernel here -- same result to fp32 summation order, not bit-identical.
+ * 256 x 256-tile kernel (conv_wgrad3) needs more slabs than fit while the paired kernel's fit (e.g. C = 256, 1x1,
+ * 256 position chunks: 64 MiB against 16) runs the paired kernel here -- same result to fp32 summation order, not bit-identical.
  * A conv whose slabs exceed the array under either kernel is rejected with an error.  The array is the one of the
  * CURRENT device (hipGetDevice), which must be the device that owns `stream`.  The call
  * allocates and frees nothing (no hipMalloc/hipFree, no allocating library routine).  All calls on one GPU share

@@ -74,10 +74,11 @@ def test_noalloc_wgrad_matches_existing_entry_point_twice_in_a_row():
 
 
 def test_noalloc_falls_back_to_the_paired_kernel_when_the_wide_kernels_slabs_do_not_fit():
-    """C = 512 single-tap conv: unet_conv1d_wgrad with a full workspace runs conv_wgrad3 (64 splits x 1 MiB = 64 MiB of
-    slabs), the allocation-free entry point's 32 MiB hold only the paired kernel's slabs -- another summation order:
-    equal at the fp32 bar, both within the bf16 bar of an fp32 F.conv1d weight gradient."""
-    case = (8, 512, 512, 512, 1, 1, 1, torch.bfloat16)       # 64 position chunks -> 64 splits for the wide kernel
+    """C = 256 single-tap conv over 256 position chunks: unet_conv1d_wgrad with a full workspace runs conv_wgrad3 on
+    its single 256 x 256 tile with 256 splits (64 MiB of slabs), the allocation-free entry point's 32 MiB hold only the
+    paired kernel's 64 splits -- another summation order: equal at the fp32 bar, both within the bf16 bar of an fp32
+    F.conv1d weight gradient."""
+    case = (4, 256, 256, 4096, 1, 1, 1, torch.bfloat16)
     dw, dw_ref, gw = _wgrad_both(case, seed=21, expect_fit=False)
     assert torch.isfinite(dw).all()
     assert ((dw - dw_ref).norm() / dw_ref.norm()).item() < 1e-5
