@@ -30,6 +30,9 @@ CASES = {
     "B": (dict(B_KW), 2, 4096, (500, 4500)),
     "B2": (dict(B_KW, skip_type="concat"), 2, 4096, (500, 4500)),
     "C": (dict(B_KW, in_channels=128, out_channels=128, n_downsample=4), 1, 4096, (500, 4500)),
+    # BASELINE.json configs[1] exactly: config B at the bench batch of 64 windows, TRAINING-mode BatchNorm over the
+    # whole batch (about half an hour of reference CPU time and ~25 GB of autograd state to generate)
+    "B64": (dict(B_KW), 64, 4096, (500, 4500)),
 }
 SLICE = 4096            # elements kept per strided slice
 

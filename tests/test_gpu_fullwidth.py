@@ -1,7 +1,8 @@
 """Parity at the widths bench.py runs (GPU).
 
 1. Whole model at BASELINE.json's configurations B / B2 / C at FULL width (base=256; C: 128 channels in/out,
-   n_downsample=4, 446 M parameters) against records frozen from the reference itself
+   n_downsample=4, 446 M parameters), and config B at the bench batch of 64 windows with training-mode BatchNorm over
+   the whole batch (B64 = BASELINE configs[1] exactly), against records frozen from the reference itself
    (oracle/make_golden_fullwidth.py -> tests/golden/fullwidth_*.npz: weights and inputs are regenerated from seeds,
    the record holds the reference's loss, checksums and strided slices of outputs / activations / gradients).
    fp32 bar: activations <= 2e-4, gradients <= 1e-3 relative L2 (north star: <= 1e-3); bf16 bars as in
@@ -70,7 +71,7 @@ def _train_forward(model, ob, ids):
     return pred, bott, acts
 
 
-@pytest.mark.parametrize("name", ["B", "B2", "C"])
+@pytest.mark.parametrize("name", ["B", "B2", "C", "B64"])
 def test_fullwidth_fp32_matches_reference(name):
     z = _record(name)
     model, ob, tgt, ids, lo, hi = _model(name, torch.float32)
@@ -109,7 +110,7 @@ def test_fullwidth_fp32_matches_reference(name):
     assert _slice_rel(pe, z, "pred_eval") < 2e-4
 
 
-@pytest.mark.parametrize("name", ["B", "B2", "C"])
+@pytest.mark.parametrize("name", ["B", "B2", "C", "B64"])
 def test_fullwidth_bf16_close_to_reference(name):
     """bf16 kernels at full width (the dispatch paths the bench times: C = 512 / 1024 / 2048, 8-32 K-chunks,
     192-wide tiles at L = 4096, the streaming single-tap kernel at C = 1024, stride-2 polyphase at C = 512)."""
