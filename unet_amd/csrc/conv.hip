@@ -1829,7 +1829,9 @@ int conv_fwd_impl(const UnetConvDesc* d, const void* x1, const void* x2, const v
       // registers per lane, the halo tile single-buffered so that two workgroups still fit a CU)
       // (unit stride only: the stride-2 data gradient of the transposed conv measured 3 % slower, scripts/bench_conv.py)
       bool want256 = d->n_taps <= 4 * d->up && d->stride == 1 && d->c_out >= 128 && !(envb && atoi(envb) != 256) &&
-                     !(k.c2 == 0 && k.c1 <= 32);
+                     !(k.c2 == 0 && k.c1 <= 32) &&
+                     !(d->n_taps == 1 && k.kctot <= 4);   // single tap over <= 256 channels (FiLM's q_proj data gradient
+                                                          // with its residual at C = 256): 110 us against 100 on 128
       for (int r = 0; r < d->up && want256; ++r)
         want256 = ph.mcount[r] > 0 && (long long)cdiv(ph.mcount[r], 256) * 256 * 100 <= (long long)ph.mcount[r] * 104;
       if (want256) {
