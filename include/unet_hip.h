@@ -107,6 +107,16 @@ int unet_conv1d_fwd_stats(const UnetConvDesc* d, const void* x1, const void* x2,
                           const float* bias, const void* res, void* y, float* s1_part, float* s2_part,
                           int32_t* parts_out, void* stream);
 
+/* FiLM's out_proj with the gate and the residual as its epilogue (models.py:515-517, `x + gate * out_proj(h)`):
+ *   y_o   = conv(x1) + bias                     (stored only when y_o is non-null: training keeps o for d gate)
+ *   y_out = res + gate[n][c] * y_o              (gate fp32 [n][c_out], 16-byte aligned; y_o as rounded to bf16)
+ * one pass instead of unet_conv1d_fwd followed by unet_gated_add_fwd, which reads o and res back and writes out.
+ * Single-tap, unit-stride bf16 convs that the streaming kernel takes only (kctot >= 3, c_out % 8 == 0, c_out <= 2048,
+ * 16-byte aligned rows); y_out has y's pitches (d->y_ld / d->y_ns).  Returns 0 when launched, 1 when the shape is not
+ * taken and NOTHING was launched (the caller then runs the two calls above), -1 on error. */
+int unet_conv1d_fwd_gated(const UnetConvDesc* d, const void* x1, const void* w_packed, const float* bias,
+                          const void* res, const float* gate, void* y_o, void* y_out, void* stream);
+
 /* Which kernel the calling thread's most recent unet_conv1d_fwd / unet_conv1d_wgrad launch used.  No
  * counterpart in the reference (cuDNN picks its algorithm internally, models.py convs); bench.py uses it
  * to attribute live launch timings to the kernel named in its roofline object. */

@@ -363,3 +363,43 @@ def test_skip_gradient_merged_in_the_data_gradient_epilogue(name):
             continue
         assert rel(grads[0][1][k], v) < 1e-5, k
     assert rel(grads[0][0], g.t("grad_ob")) < 1e-3
+
+
+def test_training_forward_never_reads_the_inference_cache():
+    """Grad mode is always off INSIDE an autograd Function's forward, so FiLM must not read "is this inference" from
+    it: a differentiated call has to pack its weights afresh (the optimizer kernels update parameters without bumping
+    their version counters, so a cached image would be stale from the second step on).  Weights are changed behind
+    the version counters' back here; the next training forward must see them and leave no cache entry behind."""
+    from unet_amd import ops
+    from unet_amd.model import FiLM
+    g = Golden("B_modern_add_bn_gelu")
+    model = _build(g, torch.bfloat16)
+    model.outc.weight.data.fill_(0.05)                     # outc is zero-initialised: make the blocks matter
+    model.train()
+    ob = g.t("ob").cuda()
+    ops.clear_pack_cache()
+    y0 = model(ob, **_kw(g)).detach().clone()
+    assert not ops._PACK_CACHE
+    films = [m for m in model.modules() if isinstance(m, FiLM) and hasattr(m, "q_proj")]
+    assert films
+    versions = [m.q_proj.weight._version for m in films]
+    for m in films:
+        m.q_proj.weight.data.mul_(1.5)
+        m.out_proj.weight.data.mul_(-1.5)
+    assert versions == [m.q_proj.weight._version for m in films]
+    y1 = model(ob, **_kw(g)).detach().clone()
+    assert not ops._PACK_CACHE
+    assert rel(y1, y0) > 1e-3
+    # ... and a cache left behind by an evaluation pass in between is not picked up by training either
+    model.eval()
+    with torch.no_grad():
+        model(ob, **_kw(g))
+    assert ops._PACK_CACHE
+    model.training = True                                   # not model.train(): that clears the cache on purpose
+    for m in model.modules():
+        m.training = True
+    for m in films:
+        m.out_proj.weight.data.mul_(-1.0)
+    y2 = model(ob, **_kw(g)).detach().clone()
+    assert rel(y2, y1) > 1e-3
+    ops.clear_pack_cache()

@@ -439,3 +439,96 @@ def test_small_cin_weight_gradient_and_half_chunk_forward(cin, kind):
         xs[:, ok] = xd[:, src[ok]]
         yr += torch.einsum("nmi,oi->nmo", xs, wq[j])
     assert rel(y, yr) < 4e-3
+
+
+GATED_CASES = [
+    # (n, c_in, c_out, L): ragged position tiles, a ragged K tail, an odd number of 128-row weight tiles, many windows
+    (4, 256, 256, 500),
+    (2, 1024, 1024, 256),
+    (3, 200, 192, 131),
+    (70, 256, 256, 129),
+    (2, 512, 512, 4096),
+]
+
+
+@pytest.mark.parametrize("keep_o", [True, False])
+@pytest.mark.parametrize("case", GATED_CASES)
+def test_gated_epilogue_of_out_proj_equals_conv_then_gated_add(case, keep_o):
+    """unet_conv1d_fwd_gated (out = res + gate * (W h + b) from the streaming kernel's epilogue) against the two
+    launches it replaces, unet_conv1d_fwd + unet_gated_add_fwd: o bit-identical, out identical up to the fused
+    multiply-add's last bit, and against fp32 torch on the bf16-rounded inputs."""
+    ops = _ops()
+    from unet_amd import _lib
+    lib = _lib.load()
+    n, cin, cout, L = case
+    g = torch.Generator().manual_seed(sum(case))
+    h = torch.randn(n, L, cin, generator=g).bfloat16().cuda()
+    res = torch.randn(n, L, cout, generator=g).bfloat16().cuda()
+    gate = torch.randn(n, cout, generator=g).cuda()
+    w = (torch.randn(1, cout, cin, generator=g) / cin ** 0.5).cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    g1 = ops.geom_conv(1)
+    wp = ops.pack_weights(w, _lib.BF16, transpose=False, tap_src=None, n_taps=1, row_lo=0, rows=cout, c1=cin, c2=0)
+    o_ref = ops.conv_forward_raw(g1, h, None, wp, b, None, L, cout)
+    out_ref = torch.empty_like(res)
+    _lib.check(lib.unet_gated_add_fwd(_lib.BF16, res.data_ptr(), o_ref.data_ptr(), gate.data_ptr(), out_ref.data_ptr(),
+                                     n, L, cout, None), "unet_gated_add_fwd")
+    out = torch.full_like(res, float("nan"))
+    o, done = ops.conv_forward_gated_raw(g1, h, wp, b, res, gate, out, keep_o=keep_o)
+    assert done, "the streaming kernel takes every shape in this list"
+    assert lib.unet_conv1d_last_variant() == 3          # UNET_VARIANT_FWD_STREAM
+    torch.cuda.synchronize()
+    if keep_o:
+        assert torch.equal(o, o_ref)
+    else:
+        assert o is None
+    assert not torch.isnan(out.float()).any()
+    diff = (out.float() - out_ref.float()).abs()
+    assert (diff <= 2.0 ** -7 * out_ref.float().abs()).all()            # at most one bf16 step apart
+    assert (diff == 0).float().mean() > 0.99
+    ref = res.float().cpu() + gate.cpu()[:, None, :] * (h.float().cpu() @ w[0].bfloat16().float().cpu().t() + b.cpu())
+    assert rel(out, ref) < 1e-2
+
+
+def test_gated_epilogue_declines_shapes_the_streaming_kernel_does_not_take():
+    """Return value 1 = nothing launched (the caller runs the two-launch path): too few K chunks, fp32."""
+    ops = _ops()
+    from unet_amd import _lib
+    g1 = ops.geom_conv(1)
+    for dtype, cin in ((torch.bfloat16, 64), (torch.float32, 256)):
+        h = torch.randn(2, 100, cin, device="cuda", dtype=dtype)
+        res = torch.randn(2, 100, 64, device="cuda", dtype=dtype)
+        gate = torch.randn(2, 64, device="cuda")
+        w = torch.randn(1, 64, cin, device="cuda")
+        wp = ops.pack_weights(w, _lib.BF16 if dtype == torch.bfloat16 else _lib.F32, transpose=False, tap_src=None,
+                              n_taps=1, row_lo=0, rows=64, c1=cin, c2=0)
+        out = torch.zeros_like(res)
+        o, done = ops.conv_forward_gated_raw(g1, h, wp, None, res, gate, out, keep_o=True)
+        assert not done and o is None
+        assert (out == 0).all()
+
+
+@pytest.mark.parametrize("case", GATED_CASES)
+def test_streamed_single_tap_conv_with_residual_equals_the_tap_loop_kernel(case, monkeypatch):
+    """y = conv + bias + res for single-tap convs (q_proj's data gradient with the residual path's gradient) now runs in
+    the streaming kernel; it rounds once, like the tap-loop kernel it replaces, so the two agree bit for bit."""
+    ops = _ops()
+    from unet_amd import _lib
+    lib = _lib.load()
+    n, cin, cout, L = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(n, L, cin, generator=g).bfloat16().cuda()
+    res = torch.randn(n, L, cout, generator=g).bfloat16().cuda()
+    w = (torch.randn(1, cout, cin, generator=g) / cin ** 0.5).cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    g1 = ops.geom_conv(1)
+    wp = ops.pack_weights(w, _lib.BF16, transpose=False, tap_src=None, n_taps=1, row_lo=0, rows=cout, c1=cin, c2=0)
+    y = ops.conv_forward_raw(g1, x, None, wp, b, res, L, cout)
+    assert lib.unet_conv1d_last_variant() == 3
+    monkeypatch.setenv("UNET_STREAM_NORES", "1")
+    y_tap = ops.conv_forward_raw(g1, x, None, wp, b, res, L, cout)
+    assert lib.unet_conv1d_last_variant() != 3
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_tap)
+    ref = res.float().cpu() + x.float().cpu() @ w[0].bfloat16().float().cpu().t() + b.cpu()
+    assert rel(y, ref) < 1e-2

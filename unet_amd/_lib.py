@@ -75,6 +75,7 @@ _SIGNATURES = {
                                          C.c_float, C.c_float, C.c_float, _vp]),
     "unet_conv1d_fwd": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "unet_conv1d_stats_max_parts": (_i32, [C.POINTER(ConvDesc)]),
+    "unet_conv1d_fwd_gated": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "unet_conv1d_fwd_stats": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp]),
     "unet_conv1d_last_variant": (C.c_int, []),
     "unet_conv1d_wgrad_workspace_bytes": (C.c_size_t, [C.POINTER(ConvDesc)]),

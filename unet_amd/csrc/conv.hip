@@ -49,6 +49,7 @@ struct ConvK {
   int xbytes;            // bytes of one input tile buffer (multiple of 1 KiB)
   int tap_row[UNET_MAX_TAPS];  // LDS row that local output position 0 reads for this tap
   float* s1; float* s2;  // conv_fwd2 only, optional: per-(window, position tile, channel) sum / sum of squares of y
+  const float* gate; char* y2;  // conv_stream gated epilogue only: y2 = res + gate[n][co] * y (y itself optional)
 };
 
 __device__ const u32x4 g_zero_chunk = {0u, 0u, 0u, 0u};  // source of padding rows for LDS-DMA staging
@@ -603,6 +604,17 @@ __device__ __forceinline__ u32x4 quad_regroup(const u32x2 a, const u32x2 b) {
   return w;
 }
 
+// the inverse: 8 consecutive channels per lane -> the accumulator layout of the two tiles (both swaps are involutions)
+__device__ __forceinline__ void quad_ungroup(const u32x4 w, u32x2& a, u32x2& b) {
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    const u32x2 t = __builtin_amdgcn_permlane16_swap(w[pp], w[2 + pp], false, false);
+    const u32x2 u = __builtin_amdgcn_permlane32_swap(t[0], t[1], false, false);
+    a[pp] = u[0];
+    b[pp] = u[1];
+  }
+}
+
 constexpr int ST_D = 3;                       // ring depth
 constexpr int ST_THREADS = 512;               // 8 waves: 4 (output-channel groups of 64) x 2 (position halves)
 constexpr int ST_BM = 256;                    // output channels per tile = two packed 128-row weight tiles
@@ -610,8 +622,50 @@ constexpr int ST_SLOT = 3 * WTILE_BYTES;      // 32 KiB weights + 16 KiB input c
 constexpr int ST_BIAS = ST_D * ST_SLOT;       // fp32 bias of every output channel (<= 8 KiB) behind the ring
 constexpr int ST_MAXC = 2048;
 
-__global__ __launch_bounds__(ST_THREADS, 1) void conv_stream_kernel(const ConvK p, const unsigned w_bytes) {
+// Epilogue operands that arrive from memory (the residual tile: 8 x 16 B per lane; FiLM's gate: 16 floats per lane)
+// are requested two steps before the epilogue that consumes them, so that their latency hides behind the stream like
+// a stage's does.  They cannot live in compiler-managed registers: loads the compiler knows about get s_waitcnt of its
+// own placing (it cannot see the counted waits of the pipeline, so it drains the queue: vmcnt(0) inside the loop),
+// and loads hidden in inline asm with compiler-allocated outputs are copied and spilled across the loop like any other
+// value, i.e. read while still in flight.  So the kernel OWNS v208..v255: amdgpu_num_vgpr caps the compiler's
+// allocation at 208 registers (it uses ~150), the loads name the owned registers in their asm text, and the epilogue
+// copies them out with v_mov after the pipeline's own wait has covered them.
+#define ST_OWNED_LOAD(I, A, B, C, D)                                                                                  \
+  case I:                                                                                                              \
+    asm volatile("buffer_load_dwordx4 v[" #A ":" #D "], %0, %1, 0 offen" ::"v"(voff), "s"(rs)                        \
+                 : "memory", "v" #A, "v" #B, "v" #C, "v" #D);                                                        \
+    break;
+#define ST_OWNED_GET(I, A, B, C, D)                                                                                   \
+  case I:                                                                                                              \
+    asm volatile("v_mov_b32 %0, v" #A "\n\tv_mov_b32 %1, v" #B "\n\tv_mov_b32 %2, v" #C "\n\tv_mov_b32 %3, v" #D       \
+                 : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]));                                                  \
+    break;
+#define ST_OWNED_ALL(X)                                                                                               \
+  X(0, 208, 209, 210, 211) X(1, 212, 213, 214, 215) X(2, 216, 217, 218, 219) X(3, 220, 221, 222, 223)                 \
+  X(4, 224, 225, 226, 227) X(5, 228, 229, 230, 231) X(6, 232, 233, 234, 235) X(7, 236, 237, 238, 239)                 \
+  X(8, 240, 241, 242, 243) X(9, 244, 245, 246, 247) X(10, 248, 249, 250, 251) X(11, 252, 253, 254, 255)
+constexpr int ST_OWNED_FIRST = 208;
+// slot i (0..7: residual rows, 8..11: gate) <- 16 bytes at voff of the buffer rs; i is a compile-time constant after unrolling
+template <class RS>
+__device__ __forceinline__ void st_owned_load(const int i, const unsigned voff, const RS rs) {
+  switch (i) { ST_OWNED_ALL(ST_OWNED_LOAD) default: break; }
+}
+__device__ __forceinline__ u32x4 st_owned_get(const int i) {
+  unsigned r[4] = {0u, 0u, 0u, 0u};
+  switch (i) { ST_OWNED_ALL(ST_OWNED_GET) default: break; }
+  return u32x4{r[0], r[1], r[2], r[3]};
+}
+
+// MODE 0: y = conv + bias.
+// MODE 1 / 2: FiLM's out_proj with its gate and residual as the epilogue (models.py:515-517):
+//   y2 = res + gate[n][co] * bf16(conv + bias); MODE 1 also stores y (training keeps o for the gate's gradient),
+//   MODE 2 does not (inference).
+// MODE 3: y = conv + bias + res (the data gradient of q_proj, which receives the residual path's gradient).
+template <int MODE>
+__global__ __launch_bounds__(ST_THREADS, 1) __attribute__((amdgpu_num_vgpr(ST_OWNED_FIRST)))
+void conv_stream_kernel_t(const ConvK p, const unsigned w_bytes) {
   typedef __bf16 T;
+  constexpr bool RES = MODE != 0, GATED = MODE == 1 || MODE == 2, KEEP_O = MODE != 2;
   constexpr int BN = 128, NI = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -707,6 +761,35 @@ __global__ __launch_bounds__(ST_THREADS, 1) void conv_stream_kernel(const ConvK 
   };
   zero_acc();
 
+  // ---- epilogue operands: residual rows and gate values of a tile, into the owned registers -------------------
+  const unsigned r_win = RES ? (unsigned)(((p.l_out - 1) * p.res_ld + p.c_out) * 2) : 0u;
+  auto issue_res = [&](int tile) {     // exactly 8 (+ 4 gated) loads per wave (out-of-range rows / channels read zeros)
+    int mt, n, m0;
+    decode(tile, mt, n, m0);
+    const auto rsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res + (long long)n * p.res_ns * 2), 0, r_win, 0x00020000);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int m = m0 + wn * (BN / 2) + ni * 16 + l15;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int co = mt * ST_BM + wm * 64 + h * 32 + lq * 8;
+        const unsigned voff = (m < p.l_out && co < p.c_out) ? (unsigned)((m * p.res_ld + co) * 2) : OOB;
+        st_owned_load(ni * 2 + h, voff, rsrd);
+      }
+    }
+    if constexpr (GATED) {
+      const auto gsrd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gate + (long long)n * p.c_out), 0,
+                                                          (unsigned)p.c_out * 4u, 0x00020000);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int co = mt * ST_BM + wm * 64 + h * 32 + lq * 8;
+        const unsigned voff = co < p.c_out ? (unsigned)(co * 4) : OOB;
+        st_owned_load(8 + 2 * h, voff, gsrd);
+        st_owned_load(9 + 2 * h, voff + 16u, gsrd);
+      }
+    }
+  };
+
   if (total > 0) {
     setup_issue_tile();
     __syncthreads();                      // bias in LDS
@@ -723,17 +806,36 @@ __global__ __launch_bounds__(ST_THREADS, 1) void conv_stream_kernel(const ConvK 
       int mt, n, m0;
       decode(tile, mt, n, m0);
       const auto ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)n * p.y_ns * 2), 0, y_win, 0x00020000);
+      const auto y2srd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y2 + (long long)n * p.y_ns * 2), 0, y_win, 0x00020000);
+      u32x4 gq[2][2];
+      if constexpr (GATED) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { gq[h][0] = st_owned_get(8 + 2 * h); gq[h][1] = st_owned_get(9 + 2 * h); }
+      }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         const int m = m0 + wn * (BN / 2) + ni * 16 + l15;
+        // MODE 3: conv + bias + res is rounded ONCE, as the tap-loop kernels do, so the residual (loaded as 8
+        // consecutive channels per lane) is first taken back to the accumulator layout
+        u32x2 ra[4];
+        if constexpr (MODE == 3) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) quad_ungroup(st_owned_get(ni * 2 + h), ra[2 * h], ra[2 * h + 1]);
+        }
         u32x2 o[4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
           const int co = mt * ST_BM + wm * 64 + mi * 16 + lq * 4;
           const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + co);
           bf16x4 v;
+          if constexpr (MODE == 3) {
+            const bf16x4 rv = __builtin_bit_cast(bf16x4, ra[mi]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (__bf16)(acc[mi][ni][r] + bv[r]);
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)(acc[mi][ni][r] + bv[r] + (float)rv[r]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)(acc[mi][ni][r] + bv[r]);
+          }
           o[mi] = __builtin_bit_cast(u32x2, v);
         }
         // An accumulator lane holds 4 channels of 4 tiles (8-byte stores, 32 contiguous bytes per row and
@@ -744,7 +846,17 @@ __global__ __launch_bounds__(ST_THREADS, 1) void conv_stream_kernel(const ConvK 
           const u32x4 w = quad_regroup(o[2 * h], o[2 * h + 1]);
           const int co = mt * ST_BM + wm * 64 + h * 32 + lq * 8;
           const unsigned voff = (m < p.l_out && co < p.c_out) ? (unsigned)((m * p.y_ld + co) * 2) : OOB;
-          __builtin_amdgcn_raw_buffer_store_b128(w, ysrd, voff, 0, 0);
+          if constexpr (GATED) {
+            if (KEEP_O) __builtin_amdgcn_raw_buffer_store_b128(w, ysrd, voff, 0, 0);
+            const bf16x8 ov = __builtin_bit_cast(bf16x8, w), rv = __builtin_bit_cast(bf16x8, st_owned_get(ni * 2 + h));
+            const f32x4 g0 = __builtin_bit_cast(f32x4, gq[h][0]), g1 = __builtin_bit_cast(f32x4, gq[h][1]);
+            bf16x8 ov2;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ov2[i] = from_f32<T>((float)rv[i] + (i < 4 ? g0[i & 3] : g1[i & 3]) * (float)ov[i]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov2), y2srd, voff, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(w, ysrd, voff, 0, 0);
+          }
         }
       }
       zero_acc();
@@ -757,22 +869,37 @@ __global__ __launch_bounds__(ST_THREADS, 1) void conv_stream_kernel(const ConvK 
     };
 
     int c_tile = 0, c_kc = 0, slot = 0, after = 0;
+    bool r_prev = false;                  // the previous step requested a residual tile (12 loads, before its stage)
     bf16x8 a0[4], b0[NI], a1[4], b1[NI];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { a1[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; b1[i] = a1[i]; }
+#pragma nounroll                          // also keeps the first step from being peeled off (a second copy of the body)
     for (int g = 0; g < total; ++g) {
       // stage g must have landed; the stage requested after it (6 loads per wave) may stay in flight -- plus, for
       // the two steps after a tile epilogue, that tile's 8 stores, which are younger than the stages that were in
       // flight when they were issued (loads and stores share the counter and retire in order)
+      // With epilogue operands: a tile's residual (/ gate) request (8 or 12 loads) goes out at the step of its
+      // second-to-last stage, BEFORE that step's stage request, so in the queue it sits between the two stages in
+      // flight at that point: the next step may leave it and the stage behind it in flight (6 + 8 or 12); the step
+      // after that waits for a stage younger than it (6), and that is the step whose second half runs the epilogue.
+      // A gated epilogue that keeps o stores 16 times per wave instead of 8.
       const int rem = total - 1 - g;
       if (rem >= 1) {
-        if (after > 0) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (RES && r_prev) {
+          if (GATED) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        } else if (after > 0) {
+          if (MODE == 1) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       if (after > 0) --after;
+      r_prev = false;
       __builtin_amdgcn_s_barrier();       // every wave's part of stage g is in LDS; stage g-1's buffer is free
+      if constexpr (RES)
+        if (c_kc == kct - 2) { issue_res(c_tile); r_prev = true; }
       if (g + ST_D - 1 < total) issue_slot(slot == 0 ? ST_D - 1 : slot - 1);
 
       const int so = slot * ST_SLOT;
@@ -814,6 +941,11 @@ __global__ __launch_bounds__(ST_THREADS, 1) void conv_stream_kernel(const ConvK 
     epilogue(c_tile - 1);
   }
 }
+
+constexpr auto conv_stream_kernel = conv_stream_kernel_t<0>;
+constexpr auto conv_stream_gated_kernel = conv_stream_kernel_t<1>;        // stores o and out
+constexpr auto conv_stream_gated_out_kernel = conv_stream_kernel_t<2>;    // stores out only
+constexpr auto conv_stream_res_kernel = conv_stream_kernel_t<3>;          // + residual
 
 // ---------------------------------------------------------------------------------------------
 // weight packing:  fp32 w[tap][row][col] (strided)  ->  [tap][row tile][K chunk][128 rows][8 chunks x 16 B]
@@ -1625,9 +1757,14 @@ int launch_stream(ConvK& k, hipStream_t st) {
   const int mt2 = (k.mtiles + 1) / 2;
   const size_t lds = ST_BIAS + (size_t)mt2 * ST_BM * sizeof(float);
   const unsigned w_bytes = (unsigned)((size_t)k.mtiles * k.kctot * WTILE_BYTES);
+  void (*kern)(const ConvK, const unsigned) =
+      k.gate ? (k.y ? conv_stream_gated_kernel : conv_stream_gated_out_kernel) : (k.res ? conv_stream_res_kernel : conv_stream_kernel);
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stream_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipSuccess;
+    void (*all[4])(const ConvK, const unsigned) = {conv_stream_kernel, conv_stream_gated_kernel, conv_stream_gated_out_kernel,
+                                                   conv_stream_res_kernel};
+    for (int i = 0; i < 4 && e == hipSuccess; ++i)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(all[i]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     UNET_REQUIRE(e == hipSuccess, "conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     int dev = 0;
     e = hipGetDevice(&dev);
@@ -1639,7 +1776,7 @@ int launch_stream(ConvK& k, hipStream_t st) {
   const long long tiles = (long long)mt2 * k.n * k.ptiles[0];
   UNET_REQUIRE(tiles > 0 && tiles < (1ll << 31), "conv: %lld tiles", tiles);
   const unsigned blocks = (unsigned)(tiles < n_cu ? tiles : n_cu);   // one persistent workgroup per CU
-  hipLaunchKernelGGL(conv_stream_kernel, dim3(blocks), dim3(ST_THREADS), lds, st, k, w_bytes);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(ST_THREADS), lds, st, k, w_bytes);
   UNET_LAUNCH_CHECK("conv_stream");
   return 0;
 }
@@ -1734,12 +1871,19 @@ extern "C" int unet_conv1d_last_variant(void) { return g_last_variant; }
 
 namespace {
 int conv_fwd_impl(const UnetConvDesc* d, const void* x1, const void* x2, const void* w_packed, const float* bias,
-                  const void* res, void* y, float* s1_part, float* s2_part, int32_t* parts_out, void* stream);
+                  const void* res, void* y, float* s1_part, float* s2_part, int32_t* parts_out, void* stream,
+                  const float* gate = nullptr, void* y2 = nullptr);
 }
 
 extern "C" int unet_conv1d_fwd(const UnetConvDesc* d, const void* x1, const void* x2, const void* w_packed,
                                const float* bias, const void* res, void* y, void* stream) {
   return conv_fwd_impl(d, x1, x2, w_packed, bias, res, y, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int unet_conv1d_fwd_gated(const UnetConvDesc* d, const void* x1, const void* w_packed, const float* bias,
+                                     const void* res, const float* gate, void* y_o, void* y_out, void* stream) {
+  UNET_REQUIRE(gate && res && y_out, "conv_fwd_gated: null pointer");
+  return conv_fwd_impl(d, x1, nullptr, w_packed, bias, res, y_o, nullptr, nullptr, nullptr, stream, gate, y_out);
 }
 
 extern "C" int32_t unet_conv1d_stats_max_parts(const UnetConvDesc* d) {
@@ -1755,9 +1899,13 @@ extern "C" int unet_conv1d_fwd_stats(const UnetConvDesc* d, const void* x1, cons
 }
 
 namespace {
+// gate != nullptr: the gated form (unet_conv1d_fwd_gated); returns 1 without launching when the streaming kernel does
+// not take the shape
 int conv_fwd_impl(const UnetConvDesc* d, const void* x1, const void* x2, const void* w_packed, const float* bias,
-                  const void* res, void* y, float* s1_part, float* s2_part, int32_t* parts_out, void* stream) {
-  UNET_REQUIRE(d && x1 && w_packed && y, "conv_fwd: null pointer");
+                  const void* res, void* y, float* s1_part, float* s2_part, int32_t* parts_out, void* stream,
+                  const float* gate, void* y2) {
+  UNET_REQUIRE(d && x1 && w_packed && (gate ? y2 != nullptr : y != nullptr), "conv_fwd: null pointer");
+  UNET_REQUIRE(!gate || (res && !x2 && d->c2 == 0), "conv_fwd_gated: needs the residual and a single source");
   if (parts_out) *parts_out = 0;
   Phases ph;
   if (analyse(d, &ph)) return -1;
@@ -1769,6 +1917,7 @@ int conv_fwd_impl(const UnetConvDesc* d, const void* x1, const void* x2, const v
   k.wp = static_cast<const char*>(w_packed); k.bias = bias; k.res = static_cast<const char*>(res);
   k.y = static_cast<char*>(y);
   k.s1 = k.s2 = nullptr;
+  k.gate = gate; k.y2 = static_cast<char*>(y2);
   const bool want_stats = s1_part && d->up == 1;       // only the tiled bf16 kernel below produces them
   k.x1_ns = d->x1_ns; k.x2_ns = d->x2_ns; k.y_ns = d->y_ns; k.res_ns = d->res_ns;
   k.x1_ld = d->x1_ld; k.x2_ld = d->x2_ld; k.y_ld = d->y_ld; k.res_ld = d->res_ld;
@@ -1784,7 +1933,7 @@ int conv_fwd_impl(const UnetConvDesc* d, const void* x1, const void* x2, const v
   const int epc = d->dtype == UNET_F32 ? 4 : 8;
   k.x1_fast = k.x1_vec && d->c1 % epc == 0;
   k.x2_fast = k.x2_vec && d->c2 % epc == 0;
-  k.y_vec = vec8_ok(y, d->y_ld, d->y_ns, es);
+  k.y_vec = vec8_ok(y ? y : y2, d->y_ld, d->y_ns, es);
   k.res_vec = res ? vec8_ok(res, d->res_ld, d->res_ns, es) : 0;
   for (int r = 0; r < 2; ++r) k.mcount[r] = ph.mcount[r];
   // tile width: 128 positions unless the halo tile would not leave room for two blocks per CU
@@ -1815,10 +1964,15 @@ int conv_fwd_impl(const UnetConvDesc* d, const void* x1, const void* x2, const v
                     2 * WTILE_BYTES + (size_t)((tg.rmax + 7) / 8) * 1024 <= 160 * 1024;
     // single-tap convs with enough K-chunks: the persistent streaming kernel (deep LDS ring)
     const char* envs = getenv("UNET_CONV_NOSTREAM");
+    const char* envr = getenv("UNET_STREAM_NORES");     // diagnostic: convs with a residual keep to the tap-loop kernel
+    const bool res_ok = res && vec_ok(res, d->res_ld, d->res_ns, 2) && (long long)d->l_out * d->res_ld * 2 < lim;
     const bool stream = v2 && !(envs && atoi(envs) == 1) && d->n_taps == 1 && d->up == 1 && d->stride == 1 && d->c2 == 0 &&
-                        k.kctot >= 3 && d->c_out <= ST_MAXC && d->c_out % 8 == 0 && !res && d->act == UNET_ACT_NONE &&
-                        vec_ok(y, d->y_ld, d->y_ns, 2) && bn == 128 && (long long)d->l_out * d->y_ld * 2 < lim;
+                        k.kctot >= 3 && d->c_out <= ST_MAXC && d->c_out % 8 == 0 && d->act == UNET_ACT_NONE &&
+                        (!y || vec_ok(y, d->y_ld, d->y_ns, 2)) && bn == 128 && (long long)d->l_out * d->y_ld * 2 < lim &&
+                        (gate ? res_ok && vec_ok(y2, d->y_ld, d->y_ns, 2) && aligned16(gate)
+                              : (!res || (res_ok && !(envr && atoi(envr) == 1))));
     if (stream) { g_last_variant = UNET_VARIANT_FWD_STREAM; return launch_stream(k, st); }
+    if (gate) return 1;
     if (v2 && bn == 128) {
       // 192 positions per tile (2/3 of the weight bytes and LDS-DMA instructions per FLOP) for many-tap convs when
       // the halo tile still leaves two workgroups per CU and the last, partial tile wastes under 4 % of the work

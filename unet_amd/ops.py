@@ -391,6 +391,27 @@ def conv_forward_raw(geom: ConvGeom, x1: Tensor, x2: Optional[Tensor], w_packed:
     return y
 
 
+FILM_GATED_EPILOGUE = os.environ.get("UNET_FILM_GATED", "1") != "0"   # 0: out_proj, then unet_gated_add_fwd (A/B)
+
+
+def conv_forward_gated_raw(geom: ConvGeom, x1: Tensor, w_packed: Tensor, bias: Optional[Tensor], res: Tensor,
+                           gate: Tensor, out: Tensor, keep_o: bool):
+    """``out = res + gate[n, c] * o`` with ``o = conv(x1) + bias`` in ONE kernel (unet_conv1d_fwd_gated).  Returns
+    ``(o or None, launched)``: ``launched`` False means the streaming kernel does not take this shape, nothing ran, and
+    the caller falls back to the conv followed by unet_gated_add_fwd.  ``o`` is stored only when ``keep_o``."""
+    lib = _lib.load()
+    n, l_out, c_out = out.shape
+    o = torch.empty_like(out) if keep_o else None
+    d = _desc(geom, x1, None, out, res, 0)
+    with _Timed("conv_fwd", geom.alg_flops(d.n, l_out, c_out, d.c1), geom.alg_scale):
+        rc = lib.unet_conv1d_fwd_gated(C.byref(d), _p(x1), _p(w_packed), _p(bias), _p(res), _p(gate), _p(o), _p(out),
+                                       _stream())
+    if rc == 1:
+        return None, False
+    check(rc, "unet_conv1d_fwd_gated")
+    return o, True
+
+
 def conv_wgrad_raw(geom: ConvGeom, x1: Tensor, x2: Optional[Tensor], dy: Tensor, c_out: int) -> Tensor:
     """dW[j][co][ci] (fp32) of the conv described by geom, from its input(s) and the output gradient."""
     lib = _lib.load()
@@ -1123,10 +1144,14 @@ class FilmFn(torch.autograd.Function):
         kf, vf, gf = _f32c(kk), _f32c(v), _f32c(g)
         pk = lambda wf: pack_weights(wf, dt, transpose=False, tap_src=None, n_taps=1, row_lo=0, rows=c, c1=c, c2=0)
         ctx.wp_dq = ctx.wp_do = None
-        if _cacheable((wq, bq, wo, bo)):
+        # grad mode is always off INSIDE an autograd Function's forward, so "is this call going to be differentiated"
+        # is read from needs_input_grad: a training call must never take the inference cache (the optimizer kernels
+        # update the weights without bumping their version counters)
+        training = any(ctx.needs_input_grad)
+        if not training and _cacheable((wq, bq, wo, bo)):
             wqp, bq32, wop, bo32 = packed_for_inference(("film", c), (wq, bq, wo, bo), dt,
                                                         lambda: (pk(wqf), _f32c(bq), pk(wof), _f32c(bo)))
-        elif DUAL_PACK and torch.is_grad_enabled() and _lib.PACK_MAX_JOBS >= 4:
+        elif DUAL_PACK and training and _lib.PACK_MAX_JOBS >= 4:
             # the two forward images and the two transposed images backward will read, in ONE launch (a pack is
             # launch-bound: four 5 us launches per block and step otherwise)
             fj = dict(transpose=False, tap_src=None, n_taps=1, row_lo=0, rows=c, c1=c, c2=0)
@@ -1139,9 +1164,12 @@ class FilmFn(torch.autograd.Function):
         q = conv_forward_raw(g1, z, None, wqp, bq32, None, rows, c)
         h = torch.empty_like(q)
         check(lib.unet_film_softmax_fwd(dt, _p(q), _p(kf), _p(vf), _p(h), n, rows, c, st), "unet_film_softmax_fwd")
-        o = conv_forward_raw(g1, h, None, wop, bo32, None, rows, c)
         out = torch.empty_like(z)
-        check(lib.unet_gated_add_fwd(dt, _p(z), _p(o), _p(gf), _p(out), n, rows, c, st), "unet_gated_add_fwd")
+        o, done = conv_forward_gated_raw(g1, h, wop, bo32, z, gf, out, keep_o=training) if FILM_GATED_EPILOGUE \
+            else (None, False)
+        if not done:
+            o = conv_forward_raw(g1, h, None, wop, bo32, None, rows, c)
+            check(lib.unet_gated_add_fwd(dt, _p(z), _p(o), _p(gf), _p(out), n, rows, c, st), "unet_gated_add_fwd")
         ctx.save_for_backward(z, q, h, o, wqf, wof, kf, vf, gf)
         ctx.dtypes = (wq.dtype, bq.dtype, wo.dtype, bo.dtype, kk.dtype, v.dtype, g.dtype)
         return out
