@@ -52,8 +52,8 @@ CROP = (500, 4500)
 BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 TRAFFIC_FILE = "r03_hbm_traffic.json"
 KERNEL_DESCR = {
-    "conv_fwd2_kernel": "conv_fwd2_kernel_128/_192 (bf16 implicit-GEMM tap-list conv, forward and data-grad launches)",
-    "conv_stream_kernel": "conv_stream_kernel (bf16 single-tap conv, persistent 256x128 tiles)",
+    "conv_fwd2_kernel": "conv_fwd2_kernel_128/_192/_256 (bf16 implicit-GEMM tap-list conv, forward and data-grad launches)",
+    "conv_stream_kernel": "conv_stream_kernel_t<0..3> (bf16 single-tap conv, persistent 256x128 tiles; plain / gated / residual epilogue)",
     "conv_wgrad2_kernel": "conv_wgrad2_kernel (bf16 weight-grad, two taps per block, split-K slabs)",
     "conv_wgrad3_kernel": "conv_wgrad3_kernel (bf16 weight-grad of single-tap convs at >= 512 channels, 256x256 tiles)",
     "conv_fwd_kernel": "conv_fwd_kernel (generic / fp32 implicit-GEMM conv)",

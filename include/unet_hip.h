@@ -201,6 +201,12 @@ int unet_bn_finalize_bwd(const float* g1_part, const float* g2_part, int32_t n, 
 int unet_reduce_rows(const float* in, int32_t rows, int32_t c, float* out, void* stream);
 /* out[n][c] = sum_p in[n][p][c]: adds the "part" partials of each window */
 int unet_reduce_parts(const float* in, int32_t n, int32_t parts, int32_t c, float* out, void* stream);
+/* Up to UNET_REDUCE_MAX_JOBS of the two reductions above in ONE launch (they are launch-bound; FiLM's backward,
+ * models.py:504-517, ends in five): for every job, out[u][c] = sum_r in[u][r][c], u < units, fp64 accumulation.
+ * unet_reduce_rows is a job with units = 1, unet_reduce_parts one with units = n and rows = parts. */
+#define UNET_REDUCE_MAX_JOBS 8
+typedef struct { const float* in; float* out; int32_t units, rows, c; } UnetReduceJob;
+int unet_reduce_multi(const UnetReduceJob* jobs, int32_t n_jobs, void* stream);
 
 /* z = act(a[n][c]*y + b[n][c]); pool_part = partial sum_t z  (norm-apply + GELU + SE squeeze,
  * models.py:559-560, 827, 649/660).  pool_part may be NULL. */

@@ -532,3 +532,23 @@ def test_streamed_single_tap_conv_with_residual_equals_the_tap_loop_kernel(case,
     assert torch.equal(y, y_tap)
     ref = res.float().cpu() + x.float().cpu() @ w[0].bfloat16().float().cpu().t() + b.cpu()
     assert rel(y, ref) < 1e-2
+
+
+def test_reduce_multi_sums_every_job_in_one_launch():
+    """unet_reduce_multi: per-window sums over parts and whole-buffer column sums of several partial buffers (different
+    widths, part counts and window counts) from one launch, against torch in fp64; more jobs than one launch takes
+    are split over launches."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(64, 8, 256), (64, 8, 256), (3, 5, 1000), (1, 1, 8), (7, 33, 40), (64, 16, 1024), (2, 300, 96),
+              (5, 2, 512), (4, 9, 64), (6, 1, 24)]
+    bufs = [torch.randn(s, generator=g).cuda() for s in shapes]
+    per_window = [i % 3 != 0 for i in range(len(shapes))]
+    outs = ops.reduce_multi(bufs, per_window)
+    assert len(outs) == len(bufs)
+    for buf, pw, out in zip(bufs, per_window, outs):
+        ref = buf.double().sum(1) if pw else buf.double().sum((0, 1))
+        assert out.shape == ref.shape
+        assert torch.allclose(out.double(), ref, rtol=1e-6, atol=1e-5)
+    with pytest.raises(ValueError):
+        ops.reduce_multi([bufs[0].transpose(1, 2)], [True])

@@ -17,6 +17,14 @@ BF16, F32 = 0, 1
 ACT_IDS = {"none": 0, "relu": 1, "leaky_relu": 2, "gelu": 3, "silu": 4, "mish": 5}
 
 
+REDUCE_MAX_JOBS = 8       # include/unet_hip.h UNET_REDUCE_MAX_JOBS
+
+
+class ReduceJob(C.Structure):
+    """include/unet_hip.h UnetReduceJob"""
+    _fields_ = [("src", C.c_void_p), ("out", C.c_void_p), ("units", C.c_int32), ("rows", C.c_int32), ("c", C.c_int32)]
+
+
 class PackJob(C.Structure):
     """Mirror of UnetPackJob (include/unet_hip.h)."""
     _fields_ = [
@@ -101,6 +109,7 @@ _SIGNATURES = {
     "unet_bn_finalize_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "unet_reduce_rows": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "unet_reduce_parts": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "unet_reduce_multi": (C.c_int, [C.POINTER(ReduceJob), _i32, _vp]),
     "unet_scale_fwd": (C.c_int, [_i32, _vp, _vp, _vp] + _row_args),
     "unet_scale_bwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp] + _row_args),
     "unet_film_softmax_fwd": (C.c_int, [_i32, _vp, _vp, _vp, _vp] + _row_args),

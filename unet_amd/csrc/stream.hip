@@ -735,6 +735,30 @@ __global__ __launch_bounds__(CS_THREADS) void reduce_rows_kernel(const float* in
   if (threadIdx.x / CS_CH == 0 && ch < c) out[ch] = (float)s[0];
 }
 
+// several reductions in ONE launch: out[u][c] = sum_r in[u][r][c] for every unit u of every job (a reduce_rows is one
+// unit, a reduce_parts is one unit per window).  These sums are launch-bound (a few microseconds each, tens of them
+// per training step); the backward of a FiLM block alone needs five.
+struct ReduceM {
+  UnetReduceJob j[UNET_REDUCE_MAX_JOBS];
+  int first[UNET_REDUCE_MAX_JOBS + 1];    // first[k] = units of jobs 0..k-1
+  int n;
+};
+__global__ __launch_bounds__(CS_THREADS) void reduce_multi_kernel(const ReduceM m) {
+  __shared__ double red[CS_SEG * CS_CH];
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < UNET_REDUCE_MAX_JOBS; ++i)
+    if (i < m.n && (int)blockIdx.y >= m.first[i]) k = i;
+  const UnetReduceJob& job = m.j[k];
+  const int u = blockIdx.y - m.first[k];
+  if ((int)blockIdx.x * CS_CH >= job.c) return;            // block-uniform: this job has fewer channels than the widest
+  const int ch = blockIdx.x * CS_CH + threadIdx.x % CS_CH;
+  const float* const src[1] = {job.in + (long long)u * job.rows * job.c};
+  double s[1];
+  column_sums<1>(src, job.rows, job.c, ch, s, red);
+  if (threadIdx.x / CS_CH == 0 && ch < job.c) job.out[(long long)u * job.c + ch] = (float)s[0];
+}
+
 // out[n][c] = sum_p in[n][p][c]   (adds the per-row-chunk partials of one window; replaces a strided
 // torch reduction over the middle axis)
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* in, int parts, int c, float* out) {
@@ -1210,6 +1234,31 @@ extern "C" int unet_reduce_rows(const float* in, int32_t rows, int32_t c, float*
   UNET_REQUIRE(in && out && rows > 0 && c > 0, "reduce_rows: bad arguments");
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(c, CS_CH)), dim3(CS_THREADS), 0, static_cast<hipStream_t>(stream), in, rows, c, out);
   UNET_LAUNCH_CHECK("reduce_rows");
+  return 0;
+}
+
+extern "C" int unet_reduce_multi(const UnetReduceJob* jobs, int32_t n_jobs, void* stream) {
+  UNET_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= UNET_REDUCE_MAX_JOBS, "reduce_multi: 1..%d jobs per call, got %d",
+               UNET_REDUCE_MAX_JOBS, n_jobs);
+  ReduceM m;
+  m.n = n_jobs;
+  int cmax = 0;
+  long long units = 0;
+  for (int i = 0; i < UNET_REDUCE_MAX_JOBS; ++i) {
+    m.j[i] = jobs[i < n_jobs ? i : 0];
+    m.first[i] = (int)units;
+    if (i < n_jobs) {
+      const UnetReduceJob& j = jobs[i];
+      UNET_REQUIRE(j.in && j.out && j.units > 0 && j.rows > 0 && j.c > 0, "reduce_multi: bad job %d", i);
+      units += j.units;
+      cmax = j.c > cmax ? j.c : cmax;
+    }
+  }
+  m.first[UNET_REDUCE_MAX_JOBS] = (int)units;
+  UNET_REQUIRE(units <= 65535, "reduce_multi: %lld units in one call (max 65535)", units);
+  hipLaunchKernelGGL(reduce_multi_kernel, dim3(cdiv(cmax, CS_CH), (unsigned)units), dim3(CS_THREADS), 0,
+                     static_cast<hipStream_t>(stream), m);
+  UNET_LAUNCH_CHECK("reduce_multi");
   return 0;
 }
 

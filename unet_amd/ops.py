@@ -737,6 +737,31 @@ def colsum(x: Tensor) -> Tensor:
     return out
 
 
+REDUCE_MULTI = os.environ.get("UNET_REDUCE_MULTI", "1") != "0"        # 0: one launch per sum (A/B measurements)
+
+
+def reduce_multi(bufs: Sequence[Tensor], per_window: Sequence[bool]) -> List[Tensor]:
+    """``sum_parts`` (per_window True: [N, P, C] -> [N, C]) and ``_reduce_all_parts`` (False: -> [C]) of several partial
+    buffers in ONE launch (unet_reduce_multi): each of these sums is a few microseconds of launch-bound work."""
+    lib = _lib.load()
+    if not REDUCE_MULTI:
+        return [sum_parts(b) if pw else _reduce_all_parts(b) for b, pw in zip(bufs, per_window)]
+    outs: List[Tensor] = []
+    for lo in range(0, len(bufs), _lib.REDUCE_MAX_JOBS):
+        chunk = list(zip(bufs, per_window))[lo:lo + _lib.REDUCE_MAX_JOBS]
+        arr = (_lib.ReduceJob * len(chunk))()
+        for i, (buf, pw) in enumerate(chunk):
+            n, p, c = buf.shape
+            if buf.dtype != torch.float32 or not buf.is_contiguous():
+                raise ValueError("reduce_multi takes contiguous fp32 [N, parts, C] buffers")
+            out = torch.empty((n, c) if pw else (c,), dtype=torch.float32, device=buf.device)
+            arr[i].src, arr[i].out = buf.data_ptr(), out.data_ptr()
+            arr[i].units, arr[i].rows, arr[i].c = (n, p, c) if pw else (1, n * p, c)
+            outs.append(out)
+        check(lib.unet_reduce_multi(arr, len(chunk), _stream()), "unet_reduce_multi")
+    return outs
+
+
 def _reduce_all_parts(buf: Tensor) -> Tensor:
     """[N, parts, C] partial column sums -> [C] (second stage of colsum)"""
     c = buf.shape[2]
@@ -1187,18 +1212,18 @@ class FilmFn(torch.autograd.Function):
         check(lib.unet_gated_add_bwd(dt, _p(o), _p(dout), _p(gf), _p(d_o), _p(dgp), _p(dop), n, rows, c, st),
               "unet_gated_add_bwd")
         dwo = conv_wgrad_raw(g1, h, None, d_o, c)
-        dbo = _reduce_all_parts(dop)                      # bias gradient of out_proj from the same pass
         dh = conv_dgrad_raw(g1, wof, d_o, rows, 0, c, wp=ctx.wp_do)
         dq = torch.empty_like(q)
         dkp, dvp, dqp = _part_buf(q, 3)
         check(lib.unet_film_softmax_bwd(dt, _p(q), _p(dh), _p(kf), _p(vf), _p(dq), _p(dkp), _p(dvp), _p(dqp), n, rows, c,
                                         st), "unet_film_softmax_bwd")
         dwq = conv_wgrad_raw(g1, z, None, dq, c)
-        dbq = _reduce_all_parts(dqp)                      # bias gradient of q_proj (same pass for C <= 512)
         dz = conv_dgrad_raw(g1, wqf, dq, rows, 0, c, res=dout, wp=ctx.wp_dq) if ctx.needs_input_grad[0] else None
+        # the five sums over partials this backward ends in, in one launch: the bias gradients of out_proj and q_proj
+        # (column sums of d_o and dq, taken in the passes above) and the gradients of the embedding maps kk, v, g
+        dbo, dbq, dk, dv, dg = reduce_multi((dop, dqp, dkp, dvp, dgp), (False, False, True, True, True))
         t = ctx.dtypes
-        return (dz, dwq.to(t[0]), dbq.to(t[1]), dwo.to(t[2]), dbo.to(t[3]), sum_parts(dkp).to(t[4]),
-                sum_parts(dvp).to(t[5]), sum_parts(dgp).to(t[6]))
+        return (dz, dwq.to(t[0]), dbq.to(t[1]), dwo.to(t[2]), dbo.to(t[3]), dk.to(t[4]), dv.to(t[5]), dg.to(t[6]))
 
 
 # ---------------------------------------------------------------------------------------------
