@@ -2,7 +2,10 @@
 latency < 100 ms at batch 1, > 1000 samples/s) plus sliding-window throughput over a long recording
 (BASELINE configs[4] shape: 32 channels, window 5000, stride 2500) on one GPU.
 
-    python scripts/bench_infer.py [--model B|phase5] [--seconds 300] [--batch 64] [--dtype bf16|fp32]
+    python scripts/bench_infer.py [--model B|phase5] [--seconds 300] [--batch 64] [--dtype bf16|fp32] [--graph]
+
+--graph         the forward replayed as one HIP graph per batch shape (unet_amd.graphs.GraphedInference) instead of
+                ~150 eager launches; the sliding-window run reuses one graph for its full batches
 
 --model B       config B (train.py / LOSO default), FiLM ON: odor ids are passed (without them the reference's FiLM is an
                 identity, models.py:505, and the workload is lighter than what training runs)
@@ -24,6 +27,7 @@ import numpy as np
 import torch
 
 import unet_amd
+from unet_amd.graphs import GraphedInference
 from unet_amd.infer import continuous_inference
 
 N_WARMUP, N_ITER = 10, 100            # phase_five/config.py:93-94
@@ -79,17 +83,21 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="windows per forward of the sliding-window reconstruction")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--window", type=int, default=5000)
+    ap.add_argument("--graph", action="store_true")
     args = ap.parse_args()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model, cfg = build(args.model, dtype)
     film = cfg["cond_mode"] != "none"
-    tag = f"model={args.model} ({'FiLM on' if film else 'cond_mode=none'}), {args.dtype}, window {args.window}"
+    tag = f"model={args.model} ({'FiLM on' if film else 'cond_mode=none'}), {args.dtype}, window {args.window}" + \
+        (", HIP graph" if args.graph else "")
     w = args.window
+    graphed = GraphedInference(model) if args.graph else None
+    call = graphed if args.graph else model
     for bs in (1, 8, 32):
         x = torch.randn(bs, 32, w, device="cuda")
         kw = {"odor_ids": torch.zeros(bs, dtype=torch.long, device="cuda")} if film else {}
-        lat = latency(model, x, kw)
-        wps = throughput(model, x, kw)
+        lat = latency(call, x, kw)
+        wps = throughput(call, x, kw)
         print(f"{tag}: batch {bs:2d}  latency mean {lat.mean():.2f} ms  p50 {np.percentile(lat, 50):.2f}  "
               f"p95 {np.percentile(lat, 95):.2f}  p99 {np.percentile(lat, 99):.2f}  |  {wps:.0f} windows/s = "
               f"{wps * w:.3e} samples/s", flush=True)
@@ -99,12 +107,14 @@ def main():
     n_windows = (signal.shape[1] - w) // s + 1
     kw = {"odor_ids": torch.zeros(n_windows, dtype=torch.long, device="cuda")} if film else None
     for _ in range(2):
-        continuous_inference(model, signal, w, s, batch_windows=args.batch, return_tensor=True, model_kwargs=kw)
+        continuous_inference(model, signal, w, s, batch_windows=args.batch, return_tensor=True, model_kwargs=kw,
+                             graphs=graphed or False)
     torch.cuda.synchronize()
     reps = 3
     t0 = time.perf_counter()
     for _ in range(reps):
-        continuous_inference(model, signal, w, s, batch_windows=args.batch, return_tensor=True, model_kwargs=kw)
+        continuous_inference(model, signal, w, s, batch_windows=args.batch, return_tensor=True, model_kwargs=kw,
+                             graphs=graphed or False)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
     print(f"{tag}: sliding-window reconstruction of {args.seconds} s x 32 ch ({n_windows} windows of {w}/{s}, batch "

@@ -154,3 +154,76 @@ def test_config_c_wide_deep_vs_oracle():
     worst = max(rel(p.grad, leaves[k].grad) for k, p in model.named_parameters()
                 if leaves[k].grad is not None and leaves[k].grad.norm() > 1e-7)
     assert worst < 1e-3, worst
+
+
+def _small_film_model():
+    import unet_amd
+    torch.manual_seed(3)
+    model = unet_amd.CondUNet1D(in_channels=8, out_channels=8, base=32, conv_type="modern", attention_type="none",
+                                activation="gelu", skip_type="add", norm_type="batch", cond_mode="cross_attn_gated",
+                                n_downsample=2).cuda()
+    with torch.no_grad():
+        model.outc.weight.normal_(0, 0.05)
+    model.set_compute_dtype(torch.bfloat16)
+    model.eval()
+    return model
+
+
+def test_graphed_inference_replays_the_eager_forward():
+    """graphs.GraphedInference: one HIP graph per input shape, bit-identical to the eager eval forward (same kernels on
+    the same packed weights), new inputs copied into the static buffers, a second shape gets its own graph, and a
+    parameter change (version counter) drops the graphs so that the next call sees the new weights."""
+    from unet_amd import ops
+    from unet_amd.graphs import GraphedInference
+    model = _small_film_model()
+    g = GraphedInference(model)
+    ops.clear_pack_cache()
+    for bs in (4, 1):
+        for seed in (0, 1):
+            gen = torch.Generator(device="cuda").manual_seed(seed)
+            x = torch.randn(bs, 8, 1024, device="cuda", generator=gen)
+            ids = torch.randint(0, 3, (bs,), device="cuda", generator=gen)
+            with torch.no_grad():
+                want = model(x, odor_ids=ids)
+            got = g(x, odor_ids=ids)
+            assert torch.equal(got, want), (bs, seed)
+    assert len(g._graphs) == 2
+    x = torch.randn(4, 8, 1024, device="cuda")
+    ids = torch.zeros(4, dtype=torch.long, device="cuda")
+    before = g(x, odor_ids=ids).clone()
+    with torch.no_grad():
+        model.outc.weight.mul_(2.0)                     # bumps the version counter
+    after = g(x, odor_ids=ids)
+    assert len(g._graphs) == 1                          # dropped and re-captured
+    with torch.no_grad():
+        want = model(x, odor_ids=ids)
+    assert torch.equal(after, want)
+    assert (after.float() - before.float()).abs().max() > 0
+    model.train()
+    with pytest.raises(RuntimeError):
+        g(x, odor_ids=ids)
+    ops.clear_pack_cache()
+
+
+def test_sliding_window_inference_with_graph_replay_equals_eager():
+    """continuous_inference(graphs=...): full batches replayed as a graph, the shorter last batch eager; same
+    reconstruction as the eager run, and a GraphedInference passed in is reused from recording to recording."""
+    from unet_amd.graphs import GraphedInference
+    from unet_amd.infer import continuous_inference
+    model = _small_film_model()
+    rng = np.random.default_rng(2)
+    sig = rng.standard_normal((8, 1024 * 12 + 100)).astype(np.float32)
+    n_windows = (sig.shape[1] - 1024) // 512 + 1
+    kw = {"odor_ids": torch.arange(n_windows, device="cuda") % 3}
+    want = continuous_inference(model, sig, 1024, 512, batch_windows=8, model_kwargs=kw)
+    got = continuous_inference(model, sig, 1024, 512, batch_windows=8, model_kwargs=kw, graphs=True)
+    assert n_windows % 8 != 0                           # there IS a ragged last batch
+    assert np.array_equal(got, want)
+    g = GraphedInference(model)
+    a = continuous_inference(model, sig, 1024, 512, batch_windows=8, model_kwargs=kw, graphs=g)
+    b = continuous_inference(model, sig * 0.5, 1024, 512, batch_windows=8, model_kwargs=kw, graphs=g)
+    assert len(g._graphs) == 1
+    assert np.array_equal(a, want)
+    assert np.array_equal(b, continuous_inference(model, sig * 0.5, 1024, 512, batch_windows=8, model_kwargs=kw))
+    with pytest.raises(ValueError):
+        continuous_inference(_small_film_model(), sig, 1024, 512, graphs=g)

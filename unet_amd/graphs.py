@@ -214,3 +214,71 @@ class GraphedTrainStep:
             self._allreduce(self.static_grads)
             self.graph_update.replay()
         return self.loss
+
+
+class GraphedInference:
+    """``model(x, **kwargs)`` in eval mode as ONE HIP graph per input shape, for serving loops and sliding-window
+    inference at a fixed batch (phase_five/benchmark.py:189-278 measures exactly this call at batch 1 / 8 / 32, where
+    the eager forward is launch-bound: ~150 launches whose enqueue costs the host more than the GPU needs to run them).
+
+    The first call with a new shape signature runs the model eagerly twice (which also fills the packed-weight cache),
+    captures one forward with the cached weight images in place (``ops.pack_cache_in_capture``: no pack launches in
+    the graph) and keeps static input / output buffers; later calls copy the inputs in and replay.  The returned
+    tensor is the STATIC output buffer: it is overwritten by the next call with the same shapes (clone it to keep it).
+    The graphs read the weight images of capture time; every call checks the parameters' version counters and storage
+    addresses and drops all graphs if one changed (``load_state_dict``, ``.to()``, an optimizer step).  An update that
+    bumps no version counter (torch's fused optimizers, ``ClipAdamW``) needs an explicit ``reset()``."""
+
+    def __init__(self, model: torch.nn.Module, warmup: int = 2, max_graphs: int = 8):
+        self.model, self.warmup, self.max_graphs = model, warmup, max_graphs
+        self._graphs = {}
+        self._stamp = None
+
+    def reset(self):
+        self._graphs.clear()
+        self._stamp = None
+
+    def _param_stamp(self):
+        return tuple((p._version, p.data_ptr()) for p in self.model.parameters()) + \
+            tuple((b._version, b.data_ptr()) for b in self.model.buffers())
+
+    @staticmethod
+    def _sig(x, kwargs):
+        def one(v):
+            return (tuple(v.shape), v.dtype, str(v.device)) if torch.is_tensor(v) else ("py", repr(v))
+        return (one(x),) + tuple((k, one(v)) for k, v in sorted(kwargs.items()))
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor, **kwargs):
+        from . import ops
+        if self.model.training:
+            raise RuntimeError("GraphedInference replays an eval-mode forward: call model.eval() first")
+        stamp = self._param_stamp()
+        if stamp != self._stamp:
+            self._graphs.clear()
+            self._stamp = stamp
+        sig = self._sig(x, kwargs)
+        entry = self._graphs.get(sig)
+        if entry is None:
+            if len(self._graphs) >= self.max_graphs:
+                self._graphs.pop(next(iter(self._graphs)))
+            sx = x.clone()
+            skw = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in kwargs.items()}
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(1, self.warmup)):
+                    self.model(sx, **skw)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with ops.pack_cache_in_capture(), torch.cuda.graph(graph, capture_error_mode=_capture_mode()):
+                sy = self.model(sx, **skw)
+            entry = (graph, sx, skw, sy, ops.pack_cache_tensors())
+            self._graphs[sig] = entry
+        graph, sx, skw, sy, _keep = entry
+        sx.copy_(x)
+        for k, v in kwargs.items():
+            if torch.is_tensor(v):
+                skw[k].copy_(v)
+        graph.replay()
+        return sy

@@ -64,7 +64,7 @@ def merge_seams(out: torch.Tensor, process_group=None):
 @torch.no_grad()
 def continuous_inference(model: torch.nn.Module, signal, window_size: int, stride: int, device="cuda",
                          overlap_mode: str = "average", batch_windows: int = 64, process_group=None,
-                         return_tensor: bool = False, model_kwargs: Optional[dict] = None):
+                         return_tensor: bool = False, model_kwargs: Optional[dict] = None, graphs=False):
     """Drop-in for phase_five/sliding_window.py:256-278: ``signal`` is ``[n_channels, n_samples]``
     (numpy or tensor); returns the continuous prediction ``[n_out_channels, n_samples]`` (numpy float32
     unless ``return_tensor``).  ``model(x, **model_kwargs)`` is called on ``[B, C, W]`` batches in eval mode; a tensor
@@ -73,7 +73,11 @@ def continuous_inference(model: torch.nn.Module, signal, window_size: int, strid
     ``process_group``: the ranks that SHARE this recording (default: all of them, each takes a contiguous range of
     windows and the seams are merged by one all-reduce).  ``dp.NO_GROUP`` = this rank alone processes the whole
     recording although ``torch.distributed`` is up: inference inside a fold-parallel LOSO job, where the other ranks
-    run other folds' models and must not be met in a collective."""
+    run other folds' models and must not be met in a collective.
+
+    ``graphs``: True, or a ``graphs.GraphedInference`` built over ``model`` (pass one to reuse its captured graphs from
+    recording to recording): the full batches are replayed as one HIP graph each instead of ~150 launches; a last,
+    shorter batch runs eagerly."""
     if overlap_mode not in _MODES:
         raise ValueError(f"Unknown overlap_mode: {overlap_mode}. Available: average, last, first")
     dev = torch.device(device)
@@ -90,6 +94,12 @@ def continuous_inference(model: torch.nn.Module, signal, window_size: int, strid
     out = None
     windows = sig.unfold(1, window_size, stride).permute(1, 0, 2) if total > 0 else None   # [total, C, W] view
     kw = model_kwargs or {}
+    graphed = None
+    if graphs:
+        from .graphs import GraphedInference
+        graphed = graphs if isinstance(graphs, GraphedInference) else GraphedInference(model)
+        if graphed.model is not model:
+            raise ValueError("the GraphedInference passed as graphs= was built over another model")
     done = 0
     while done < shard.n_windows:
         nb = min(batch_windows, shard.n_windows - done)
@@ -97,7 +107,7 @@ def continuous_inference(model: torch.nn.Module, signal, window_size: int, strid
         # a tensor keyword with one entry per window of the recording (odor_ids, cond_emb) is sliced with the batch
         kwb = {k: (v[first:first + nb] if (torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == total) else v)
                for k, v in kw.items()}
-        pred = model(windows[first:first + nb], **kwb)
+        pred = (graphed if (graphed is not None and nb == batch_windows) else model)(windows[first:first + nb], **kwb)
         if isinstance(pred, tuple):
             pred = pred[0]
         if out is None:

@@ -651,9 +651,35 @@ def clear_pack_cache():
     _PACK_CACHE.clear()
 
 
+_CACHE_IN_CAPTURE = False
+
+
+class pack_cache_in_capture:
+    """Context manager for the capture of an INFERENCE graph (graphs.GraphedInference): cached weight images may be
+    used while capturing, so the graph holds the convs alone and not the ~40 pack launches of a forward pass.  The
+    graph then reads the cached tensors on every replay: whoever captures under this must keep them alive
+    (``pack_cache_tensors``) and re-capture when a parameter changes."""
+
+    def __enter__(self):
+        global _CACHE_IN_CAPTURE
+        self.prev, _CACHE_IN_CAPTURE = _CACHE_IN_CAPTURE, True
+        return self
+
+    def __exit__(self, *exc):
+        global _CACHE_IN_CAPTURE
+        _CACHE_IN_CAPTURE = self.prev
+        return False
+
+
+def pack_cache_tensors() -> list:
+    """Every tensor the pack cache holds right now (a capture under ``pack_cache_in_capture`` keeps this list so that
+    clearing the cache later cannot free memory its graph still reads)."""
+    return [t for entry in _PACK_CACHE.values() for t in entry[1] if torch.is_tensor(t)]
+
+
 def _cacheable(params) -> bool:
     return (params is not None and not torch.is_grad_enabled() and os.environ.get("UNET_PACK_CACHE", "1") != "0"
-            and not torch.cuda.is_current_stream_capturing())
+            and (_CACHE_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()))
 
 
 def packed_for_inference(tag, params: Sequence[Tensor], dtype: int, build):
