@@ -448,6 +448,10 @@ GATED_CASES = [
     (3, 200, 192, 131),
     (70, 256, 256, 129),
     (2, 512, 512, 4096),
+    # exactly three K chunks: the next tile's operand request falls between a tile's stores and the wait that counts them
+    (2, 192, 256, 700),
+    (5, 136, 8, 300),
+    (9, 192, 520, 1000),
 ]
 
 

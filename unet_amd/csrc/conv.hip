@@ -78,7 +78,6 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 template <bool F32, int BN>
 __global__ __launch_bounds__(THREADS, 2) void conv_fwd_kernel(const ConvK p) {
   typedef typename Elem<F32>::T T;
-  constexpr int ES = Elem<F32>::SIZE;
   constexpr int EPC = Elem<F32>::EPC;
   constexpr int KC = EPC * 8;          // K elements per 128-byte LDS row
   constexpr int NI = BN / 32;          // 16-wide position fragments per wave

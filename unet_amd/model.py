@@ -86,6 +86,26 @@ HOIST_FILM = os.environ.get("UNET_HOIST_FILM", "1") != "0"   # 0: per-block FiLM
 FUSE_SE = os.environ.get("UNET_FUSE_SE", "1") != "0"    # 0: the unfused kernels (A/B measurements)
 
 
+def _bn_eval_affine(norm: nn.BatchNorm1d, n: int):
+    """Eval-mode BatchNorm as ``a * y + b``: the [N, C] fp32 coefficient arrays the row kernels take, from the running
+    statistics (fp64 arithmetic).  Under no_grad they are cached like the packed weight images (``ops._PACK_CACHE``,
+    revalidated against the buffers' / parameters' version counters): the dozen tiny torch launches that derive them
+    are most of what a batch-1 forward used to launch per block."""
+    def build():
+        rstd = torch.rsqrt(norm.running_var.double() + norm.eps)
+        g = norm.weight.detach().double() if norm.weight is not None else torch.ones_like(rstd)
+        bt = norm.bias.detach().double() if norm.bias is not None else torch.zeros_like(rstd)
+        a = (rstd * g).float()
+        b = (bt - norm.running_mean.double() * rstd * g).float()
+        c = a.shape[0]
+        return a[None, :].expand(n, c).contiguous(), b[None, :].expand(n, c).contiguous()
+
+    params = tuple(t for t in (norm.running_mean, norm.running_var, norm.weight, norm.bias) if t is not None)
+    if ops._cacheable(params):
+        return ops.packed_for_inference(("bn_eval_affine", n, float(norm.eps)), params, 0, build)
+    return build()
+
+
 def _norm_act_se(y: Tensor, norm: nn.Module, act_id: int, se: "SqueezeExcitation1D") -> Tensor:
     """SE(act(norm(y))) for y in NLC (models.py:801-839).  Training-mode BatchNorm -- the production path -- is one
     fused autograd node; every other norm takes the general kernels followed by the SE scale."""
@@ -93,14 +113,8 @@ def _norm_act_se(y: Tensor, norm: nn.Module, act_id: int, se: "SqueezeExcitation
         return _norm_act(y, norm, act_id, False, se=se)
     if FUSE_SE and isinstance(norm, nn.BatchNorm1d) and not torch.is_grad_enabled() and y.is_cuda:
         # eval-mode BatchNorm under no_grad (sliding-window inference, evaluate()): running statistics as the affine
-        n, _, c = y.shape
-        rstd = torch.rsqrt(norm.running_var.double() + norm.eps)
-        g = norm.weight.detach().double() if norm.weight is not None else torch.ones_like(rstd)
-        bt = norm.bias.detach().double() if norm.bias is not None else torch.zeros_like(rstd)
-        a = (rstd * g).float()
-        b = (bt - norm.running_mean.double() * rstd * g).float()
-        return ops.norm_act_se_inference(y, a[None, :].expand(n, c).contiguous(), b[None, :].expand(n, c).contiguous(),
-                                         act_id, se.fc[0].weight, se.fc[2].weight)
+        a, b = _bn_eval_affine(norm, y.shape[0])
+        return ops.norm_act_se_inference(y, a, b, act_id, se.fc[0].weight, se.fc[2].weight)
     z, pool = _norm_act(y, norm, act_id, True)
     return ops.ScaleFn.apply(z, se.gate_from_pool(pool, z.shape[1]))
 
