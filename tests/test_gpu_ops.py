@@ -452,6 +452,7 @@ GATED_CASES = [
     (2, 192, 256, 700),
     (5, 136, 8, 300),
     (9, 192, 520, 1000),
+    (64, 192, 256, 2048),       # ... with eight tiles per workgroup
 ]
 
 
