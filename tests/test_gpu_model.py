@@ -239,6 +239,8 @@ def test_inference_reuses_packed_weights_until_a_parameter_changes():
         y0 = model(ob, **_kw(g))
         n_entries = len(ops._PACK_CACHE)
         assert n_entries >= 10
+        assert any(k[0][0] == "film" for k in ops._PACK_CACHE)            # FiLM's projections are cached too
+        assert any(k[0][0] == "bn_eval_affine" for k in ops._PACK_CACHE)  # ... and eval BatchNorm's coefficients
         snapshot = {k: v[1][0].data_ptr() for k, v in ops._PACK_CACHE.items()}
         y1 = model(ob, **_kw(g))
         assert torch.equal(y0, y1)

@@ -432,8 +432,9 @@ class FiLM(nn.Module):
             kk, v, g = pre[1:]
         else:                                           # stand-alone use: one launch for this module's three maps
             kk, v, g = ops.small_linear_group(emb, self.emb_maps())
-        return ops.FilmFn.apply(x, self.q_proj.weight.permute(2, 0, 1), self.q_proj.bias,
-                                self.out_proj.weight.permute(2, 0, 1), self.out_proj.bias, kk, v, g)
+        return ops.film(x, self.q_proj.weight.permute(2, 0, 1), self.q_proj.bias,
+                        self.out_proj.weight.permute(2, 0, 1), self.out_proj.bias, kk, v, g,
+                        params=(self.q_proj.weight, self.q_proj.bias, self.out_proj.weight, self.out_proj.bias))
 
     def forward(self, x: Tensor, emb: Optional[Tensor] = None) -> Tensor:
         if self.cond_mode == "none" or emb is None:

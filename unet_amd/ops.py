@@ -1184,7 +1184,12 @@ class FilmFn(torch.autograd.Function):
     separate full-tensor add, and q / h / o are kept exactly once."""
 
     @staticmethod
-    def forward(ctx, z, wq, bq, wo, bo, kk, v, g):
+    def forward(ctx, z, wq, bq, wo, bo, kk, v, g, differentiated=None, cache_params=None):
+        """``differentiated``: will this call be back-propagated (``film`` below passes it)?  It cannot be read in
+        here: grad mode is always off inside an autograd Function's forward, and ``ctx.needs_input_grad`` only repeats
+        the inputs' ``requires_grad`` flags -- True for the parameters under ``torch.no_grad()`` as well.
+        ``cache_params``: the Parameter objects the weights derive from (``wq`` / ``wo`` are usually fresh permuted
+        views, which cannot key a cache); with them an inference call reuses the packed images."""
         lib = _lib.load()
         _need_cuda(z)
         z = _nlc_ok(z)
@@ -1195,12 +1200,11 @@ class FilmFn(torch.autograd.Function):
         kf, vf, gf = _f32c(kk), _f32c(v), _f32c(g)
         pk = lambda wf: pack_weights(wf, dt, transpose=False, tap_src=None, n_taps=1, row_lo=0, rows=c, c1=c, c2=0)
         ctx.wp_dq = ctx.wp_do = None
-        # grad mode is always off INSIDE an autograd Function's forward, so "is this call going to be differentiated"
-        # is read from needs_input_grad: a training call must never take the inference cache (the optimizer kernels
-        # update the weights without bumping their version counters)
-        training = any(ctx.needs_input_grad)
-        if not training and _cacheable((wq, bq, wo, bo)):
-            wqp, bq32, wop, bo32 = packed_for_inference(("film", c), (wq, bq, wo, bo), dt,
+        # a differentiated (training) call must never take the inference cache: the optimizer kernels update the
+        # weights without bumping their version counters
+        training = any(ctx.needs_input_grad) if differentiated is None else bool(differentiated)
+        if not training and _cacheable(cache_params):
+            wqp, bq32, wop, bo32 = packed_for_inference(("film", c), tuple(cache_params), dt,
                                                         lambda: (pk(wqf), _f32c(bq), pk(wof), _f32c(bo)))
         elif DUAL_PACK and training and _lib.PACK_MAX_JOBS >= 4:
             # the two forward images and the two transposed images backward will read, in ONE launch (a pack is
@@ -1249,7 +1253,15 @@ class FilmFn(torch.autograd.Function):
         # (column sums of d_o and dq, taken in the passes above) and the gradients of the embedding maps kk, v, g
         dbo, dbq, dk, dv, dg = reduce_multi((dop, dqp, dkp, dvp, dgp), (False, False, True, True, True))
         t = ctx.dtypes
-        return (dz, dwq.to(t[0]), dbq.to(t[1]), dwo.to(t[2]), dbo.to(t[3]), dk.to(t[4]), dv.to(t[5]), dg.to(t[6]))
+        return (dz, dwq.to(t[0]), dbq.to(t[1]), dwo.to(t[2]), dbo.to(t[3]), dk.to(t[4]), dv.to(t[5]), dg.to(t[6]), None, None)
+
+
+def film(z: Tensor, wq: Tensor, bq: Tensor, wo: Tensor, bo: Tensor, kk: Tensor, v: Tensor, g: Tensor,
+         params: Optional[Sequence[Tensor]] = None) -> Tensor:
+    """``FilmFn`` with the one fact its forward cannot find out itself: whether autograd is recording this call.
+    ``params``: the parameters behind ``wq, bq, wo, bo`` (see ``FilmFn.forward``)."""
+    diff = torch.is_grad_enabled() and any(t.requires_grad for t in (z, wq, bq, wo, bo, kk, v, g))
+    return FilmFn.apply(z, wq, bq, wo, bo, kk, v, g, diff, tuple(params) if params is not None else None)
 
 
 # ---------------------------------------------------------------------------------------------
