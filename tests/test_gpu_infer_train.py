@@ -202,6 +202,16 @@ def test_graphed_inference_replays_the_eager_forward():
     model.train()
     with pytest.raises(RuntimeError):
         g(x, odor_ids=ids)
+    # a training phase in between (the optimizer kernels bump no version counter; model.train() drops the pack cache,
+    # and with it the graphs): weights changed behind the counters are seen after the return to eval mode
+    n_cap = g.captures
+    model.outc.weight.data.mul_(0.5)
+    model.eval()
+    again = g(x, odor_ids=ids)
+    assert g.captures == n_cap + 1
+    with torch.no_grad():
+        assert torch.equal(again, model(x, odor_ids=ids))
+    assert (again.float() - after.float()).abs().max() > 0
     ops.clear_pack_cache()
 
 
@@ -222,7 +232,7 @@ def test_sliding_window_inference_with_graph_replay_equals_eager():
     g = GraphedInference(model)
     a = continuous_inference(model, sig, 1024, 512, batch_windows=8, model_kwargs=kw, graphs=g)
     b = continuous_inference(model, sig * 0.5, 1024, 512, batch_windows=8, model_kwargs=kw, graphs=g)
-    assert len(g._graphs) == 1
+    assert len(g._graphs) == 1 and g.captures == 1      # captured once, replayed for both recordings
     assert np.array_equal(a, want)
     assert np.array_equal(b, continuous_inference(model, sig * 0.5, 1024, 512, batch_windows=8, model_kwargs=kw))
     with pytest.raises(ValueError):

@@ -226,20 +226,24 @@ class GraphedInference:
     the graph) and keeps static input / output buffers; later calls copy the inputs in and replay.  The returned
     tensor is the STATIC output buffer: it is overwritten by the next call with the same shapes (clone it to keep it).
     The graphs read the weight images of capture time; every call checks the parameters' version counters and storage
-    addresses and drops all graphs if one changed (``load_state_dict``, ``.to()``, an optimizer step).  An update that
-    bumps no version counter (torch's fused optimizers, ``ClipAdamW``) needs an explicit ``reset()``."""
+    addresses and the pack cache's generation (``ops.clear_pack_cache()`` runs on ``model.train()``,
+    ``load_state_dict`` and ``.to()``) and drops all graphs if one moved.  That covers training in between: the
+    optimizer kernels bump no version counter, but a model cannot be trained without ``model.train()``.  Weights
+    written behind all of these (``p.data`` arithmetic in eval mode) need an explicit ``reset()``."""
 
     def __init__(self, model: torch.nn.Module, warmup: int = 2, max_graphs: int = 8):
         self.model, self.warmup, self.max_graphs = model, warmup, max_graphs
         self._graphs = {}
         self._stamp = None
+        self.captures = 0            # graphs captured so far (tests, diagnostics)
 
     def reset(self):
         self._graphs.clear()
         self._stamp = None
 
     def _param_stamp(self):
-        return tuple((p._version, p.data_ptr()) for p in self.model.parameters()) + \
+        from . import ops
+        return (ops.pack_cache_generation(),) + tuple((p._version, p.data_ptr()) for p in self.model.parameters()) + \
             tuple((b._version, b.data_ptr()) for b in self.model.buffers())
 
     @staticmethod
@@ -275,6 +279,7 @@ class GraphedInference:
                 sy = self.model(sx, **skw)
             entry = (graph, sx, skw, sy, ops.pack_cache_tensors())
             self._graphs[sig] = entry
+            self.captures += 1
         graph, sx, skw, sy, _keep = entry
         sx.copy_(x)
         for k, v in kwargs.items():

@@ -83,7 +83,10 @@ def continuous_inference(model: torch.nn.Module, signal, window_size: int, strid
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError("unet_amd.infer runs on the GPU only; there is no CPU path")
-    model = model.to(dev)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    if any(t.device != dev for t in list(model.parameters()) + list(model.buffers())):
+        model = model.to(dev)          # (an unconditional .to() would drop the packed-weight cache on every call)
     model.eval()
     sig = torch.as_tensor(signal)
     if sig.dtype not in (torch.float32, torch.bfloat16):

@@ -647,8 +647,19 @@ class ConvFn(torch.autograd.Function):
 _PACK_CACHE = {}
 
 
+_PACK_GENERATION = 0     # bumped by every clear: what a captured inference graph checks before it replays
+
+
 def clear_pack_cache():
+    global _PACK_GENERATION
+    _PACK_GENERATION += 1
     _PACK_CACHE.clear()
+
+
+def pack_cache_generation() -> int:
+    """Counts ``clear_pack_cache()`` calls (``CondUNet1D.train()``, ``load_state_dict``, ``.to()``): a graph captured
+    over cached weight images (``graphs.GraphedInference``) is stale once this has moved."""
+    return _PACK_GENERATION
 
 
 _CACHE_IN_CAPTURE = False
